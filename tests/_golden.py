@@ -1,0 +1,95 @@
+"""Helpers shared by the golden-fixture tests: fixture loading and the mapping from a
+fixture's ``spec`` (which names the reference entry point that produced it) to
+an oracle call."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def csr_from(z, prefix):
+    shape = tuple(int(x) for x in z[prefix + "_shape"])
+    return csr_matrix((z[prefix + "_data"], z[prefix + "_indices"], z[prefix + "_indptr"]), shape=shape)
+
+
+def spec_of(z, name=None):
+    key = "spec" if name is None else "spec_" + name
+    return json.loads(str(z[key]))
+
+
+# reference wrapper -> (base metric name, aggregation, maximize, skip_tn, mixed, default init)
+# (block_coordinate.py:762-801, :804-835, :848-1045)
+ENTRY_TABLE = {
+    "predict_optimizing_macro_precision_using_bc": ("precision", "mean", True, True, False, "top"),
+    "predict_optimizing_macro_recall_using_bc": ("recall", "mean", True, True, False, "top"),
+    "predict_optimizing_macro_f1_score_using_bc": ("f1", "mean", True, True, False, "top"),
+    "predict_optimizing_macro_jaccard_score_using_bc": ("jaccard", "mean", True, True, False, "top"),
+    "predict_optimizing_macro_balanced_accuracy_using_bc": ("balanced_accuracy", "mean", True, False, False, "top"),
+    "predict_optimizing_macro_hmean_using_bc": ("hmean", "mean", True, False, False, "top"),
+    "predict_optimizing_macro_gmean_using_bc": ("gmean", "mean", True, False, False, "top"),
+    "predict_optimizing_instance_precision_using_bc": ("precision_at_k", "sum", True, False, False, "random"),
+    "predict_optimizing_mixed_instance_precision_and_macro_precision_using_bc": ("precision", "sum", True, True, True, "top"),
+    "predict_optimizing_mixed_instance_precision_and_macro_recall_using_bc": ("recall", "sum", True, True, True, "top"),
+    "predict_optimizing_mixed_instance_precision_and_macro_f1_score_using_bc": ("f1", "sum", True, True, True, "top"),
+    "predict_optimizing_mixed_instance_precision_and_macro_balanced_accuracy_using_bc": ("balanced_accuracy", "sum", True, True, True, "top"),
+    "predict_optimizing_mixed_instance_precision_and_macro_jaccard_score_using_bc": ("jaccard", "sum", True, True, True, "top"),
+    "predict_optimizing_mixed_instance_precision_and_macro_gmean_using_bc": ("gmean", "sum", True, True, True, "top"),
+    "predict_optimizing_mixed_instance_precision_and_macro_hmean_using_bc": ("hmean", "sum", True, True, True, "top"),
+}
+
+GENERIC_METRIC_NAMES = {
+    "binary_precision_at_k_on_conf_matrix": "precision_at_k",
+    "binary_precision_on_conf_matrix": "precision",
+    "binary_recall_on_conf_matrix": "recall",
+    "binary_fbeta_score_on_conf_matrix": "fbeta",
+    "binary_f1_score_on_conf_matrix": "f1",
+    "binary_jaccard_score_on_conf_matrix": "jaccard",
+    "binary_balanced_accuracy_on_conf_matrix": "balanced_accuracy",
+    "binary_gmean_on_conf_matrix": "gmean",
+    "binary_hmean_on_conf_matrix": "hmean",
+    "binary_accuracy_on_conf_matrix": "accuracy",
+}
+
+
+def oracle_call_from_spec(oref, spec, y_proba, init_matrix=None):
+    """Run the oracle's BCA driver the way the reference entry point named in
+    `spec` would run the reference's."""
+    k = spec["k"]
+    kw = dict(spec.get("kwargs", {}))
+    m = y_proba.shape[1]
+    base_ids = {
+        "precision_at_k": oref.PRECISION_AT_K, "precision": oref.PRECISION, "recall": oref.RECALL,
+        "fbeta": oref.FBETA, "f1": oref.FBETA, "jaccard": oref.JACCARD,
+        "balanced_accuracy": oref.BALANCED_ACC, "gmean": oref.GMEAN, "hmean": oref.HMEAN,
+        "accuracy": oref.ACCURACY,
+    }
+    if spec["entry"] == "generic":
+        base = GENERIC_METRIC_NAMES[spec["metric"]]
+        agg = kw.pop("metric_aggregation", "mean")
+        maximize = kw.pop("maximize", True)
+        skip_tn = kw.pop("skip_tn", False)
+        mixed = False
+        init_default = "top"
+    else:
+        base, agg, maximize, skip_tn, mixed, init_default = ENTRY_TABLE[spec["entry"]]
+    mk = kw.pop("metric_kwargs", None) or {}
+    alpha = kw.pop("alpha", 1.0)
+    metric = oref.make_metric(base_ids[base], epsilon=mk.get("epsilon", 1e-9), beta=mk.get("beta", 1.0),
+                              k=float(k), mixed=mixed, alpha=alpha, m=float(m))
+    # _calculate_utility never receives metric_kwargs (block_coordinate.py:438-445)
+    utility_metric = oref.make_metric(base_ids[base], k=float(k), mixed=mixed, alpha=alpha, m=float(m))
+    init = kw.pop("init_y_pred", init_default)
+    if spec.get("has_init_matrix"):
+        init = init_matrix
+    return oref.predict_using_bc_with_0approx(
+        y_proba, metric, k, metric_aggregation=agg, maximize=maximize, skip_tn=skip_tn,
+        init_y_pred=init, utility_metric=utility_metric, **kw)

@@ -1,0 +1,397 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the reference itself.
+
+Run once, in the build container (needs /root/reference; the GPU box never
+sees it):
+
+    python tests/golden/make_golden.py
+
+The reference (mwydmuch/xCOLUMNs 0.0.3) is pure Python whose only compiled
+dependency, numba, is not installable offline.  Every ``@njit`` body on this
+path is plain numpy-compatible Python, so the script registers an in-memory
+module named ``numba`` whose ``njit``/``jit`` are identity decorators and
+``prange`` is ``range``; the reference's own code then runs unmodified and its
+outputs are stored here as data (inputs + expected outputs).  No reference
+source is copied.
+
+Known differences between this un-JIT'd run and real numba:
+tie choice inside np.argpartition (fixtures have no ties at the k-th
+boundary -- checked below for the top-k cases), and the random stream of
+``numba_random_at_k`` (CPython's ``random`` here).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = os.environ.get("XCOLUMNS_REFERENCE", "/root/reference")
+
+
+def _install_numba_identity():
+    mod = types.ModuleType("numba")
+
+    def _deco(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda f: f
+
+    mod.njit = mod.jit = _deco
+    mod.prange = range
+    mod.get_num_threads = lambda: 1
+    mod.set_num_threads = lambda n: None
+    sys.modules["numba"] = mod
+
+
+_install_numba_identity()
+sys.path.insert(0, REFERENCE)
+
+import xcolumns.block_coordinate as ref_bc  # noqa: E402
+import xcolumns.metrics as ref_metrics  # noqa: E402
+from xcolumns.confusion_matrix import calculate_confusion_matrix  # noqa: E402
+from xcolumns.weighted_prediction import predict_weighted_per_instance  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def csr_fields(prefix, mat):
+    return {
+        prefix + "_data": mat.data,
+        prefix + "_indices": mat.indices,
+        prefix + "_indptr": mat.indptr,
+        prefix + "_shape": np.asarray(mat.shape, dtype=np.int64),
+    }
+
+
+def ragged_csr(rng, n, m, rmax, dtype, zipf=False):
+    """Random CSR with 0..rmax sorted distinct columns per row (includes empty
+    rows and rows shorter than k)."""
+    indptr = [0]
+    cols = []
+    if zipf:
+        w = 1.0 / np.arange(1, m + 1)
+        w /= w.sum()
+        perm = rng.permutation(m)
+    for i in range(n):
+        r = int(rng.integers(0, rmax + 1))
+        if i < 4:
+            r = i  # rows with 0,1,2,3 entries for sure
+        if zipf:
+            c = perm[rng.choice(m, size=r, replace=False, p=w)]
+        else:
+            c = rng.choice(m, size=r, replace=False)
+        cols.append(np.sort(c))
+        indptr.append(indptr[-1] + r)
+    indices = np.concatenate(cols).astype(np.int32)
+    data = rng.random(indices.size).astype(dtype)
+    return csr_matrix((data, indices, np.asarray(indptr, dtype=np.int32)), shape=(n, m))
+
+
+def fixed_csr(rng, n, m, r, dtype, zipf=False, skew=False):
+    """Random CSR with exactly r sorted distinct columns per row."""
+    if zipf:
+        w = 1.0 / np.arange(1, m + 1)
+        w /= w.sum()
+        perm = rng.permutation(m)
+        cols = np.concatenate([np.sort(perm[rng.choice(m, r, replace=False, p=w)]) for _ in range(n)])
+    else:
+        cols = np.concatenate([np.sort(rng.choice(m, r, replace=False)) for _ in range(n)])
+    data = rng.random(n * r)
+    if skew:
+        data = data ** 3
+    return csr_matrix((data.astype(dtype), cols.astype(np.int32),
+                       (np.arange(n + 1) * r).astype(np.int32)), shape=(n, m))
+
+
+def assert_no_boundary_ties_csr(mat, k, a=None, b=None):
+    for i in range(mat.shape[0]):
+        s, e = mat.indptr[i], mat.indptr[i + 1]
+        g = mat.data[s:e]
+        if a is not None:
+            g = g * a[mat.indices[s:e]].astype(mat.dtype)
+        if b is not None:
+            g = g + b[mat.indices[s:e]].astype(mat.dtype)
+        if g.size > k:
+            gs = np.sort(g)[::-1]
+            assert gs[k - 1] != gs[k], f"tie at the top-k boundary in row {i}"
+
+
+# ---------------------------------------------------------------------------
+# A. weighted top-k, CSR
+# ---------------------------------------------------------------------------
+
+def gen_topk_csr():
+    for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        rng = np.random.default_rng(101 if tag == "f32" else 102)
+        n, m, k = 300, 120, 3
+        Y = ragged_csr(rng, n, m, 30, dtype)
+        a = (rng.random(m) * 2).astype(np.float64)
+        b = (rng.random(m) - 0.5).astype(np.float64)
+        assert_no_boundary_ties_csr(Y, k)
+        assert_no_boundary_ties_csr(Y, k, a, b)
+        out = {}
+        out.update(csr_fields("y", Y))
+        out["a"] = a
+        out["b"] = b
+        out["k"] = np.int64(k)
+        cases = {
+            "plain": dict(),
+            "scores": dict(keep_scores=True),
+            "ab": dict(a=a, b=b),
+            "ab_scores": dict(a=a, b=b, keep_scores=True),
+            "a_only": dict(a=a),
+            "b_only": dict(b=b),
+        }
+        for name, kw in cases.items():
+            P = predict_weighted_per_instance(Y, k, **kw)
+            assert P.dtype == dtype
+            out.update(csr_fields("pred_" + name, P))
+        # k = 0: threshold on the gains
+        th = 0.4
+        P0 = predict_weighted_per_instance(Y, 0, th=th, a=a, b=b)
+        out["th"] = np.float64(th)
+        out.update(csr_fields("pred_k0_ab", P0))
+        P0 = predict_weighted_per_instance(Y, 0, th=th)
+        out.update(csr_fields("pred_k0_plain", P0))
+        save("topk_csr_" + tag, **out)
+
+
+# ---------------------------------------------------------------------------
+# B. weighted top-k, dense
+# ---------------------------------------------------------------------------
+
+def gen_topk_dense():
+    for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        rng = np.random.default_rng(201 if tag == "f32" else 202)
+        n, m, k = 200, 60, 3
+        Y = rng.random((n, m)).astype(dtype)
+        a = (rng.random(m) * 2).astype(np.float64)
+        b = (rng.random(m) - 0.5).astype(np.float64)
+        a32 = a.astype(np.float32)
+        b32 = b.astype(np.float32)
+        out = {"y": Y, "a": a, "b": b, "a32": a32, "b32": b32, "k": np.int64(k)}
+        out["pred_plain"] = predict_weighted_per_instance(Y, k)
+        out["pred_scores"] = predict_weighted_per_instance(Y, k, keep_scores=True)
+        out["pred_ab"] = predict_weighted_per_instance(Y, k, a=a, b=b)
+        out["pred_ab_scores"] = predict_weighted_per_instance(Y, k, a=a, b=b, keep_scores=True)
+        out["pred_ab32"] = predict_weighted_per_instance(Y, k, a=a32, b=b32)
+        out["pred_ab32_scores"] = predict_weighted_per_instance(Y, k, a=a32, b=b32, keep_scores=True)
+        th = 0.6
+        out["th"] = np.float64(th)
+        out["pred_k0_ab"] = predict_weighted_per_instance(Y, 0, th=th, a=a, b=b)
+        out["pred_k0_plain"] = predict_weighted_per_instance(Y, 0, th=th)
+        for key in list(out):
+            if key.startswith("pred_"):
+                assert out[key].dtype == dtype and out[key].shape == (n, m)
+        save("topk_dense_" + tag, **out)
+
+
+# ---------------------------------------------------------------------------
+# C. confusion matrix
+# ---------------------------------------------------------------------------
+
+def gen_confusion():
+    for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        rng = np.random.default_rng(301 if tag == "f32" else 302)
+        n, m, k = 400, 90, 4
+        Y = ragged_csr(rng, n, m, 25, dtype)
+        P = predict_weighted_per_instance(Y, k)       # includes rows with r < k (padding quirk)
+        # a prediction with entries outside the support of Y
+        Prand = fixed_csr(rng, n, m, k, dtype)
+        Prand.data[:] = 1
+        # binary ground truth as float CSR
+        L = ragged_csr(rng, n, m, 6, dtype)
+        L.data[:] = 1
+        out = {}
+        out.update(csr_fields("y", Y))
+        out.update(csr_fields("p", P))
+        out.update(csr_fields("prand", Prand))
+        out.update(csr_fields("l", L))
+        for tname, T_ in (("y", Y), ("l", L)):
+            for pname, P_ in (("p", P), ("prand", Prand)):
+                for skip_tn in (False, True):
+                    for normalize in (False, True):
+                        C = calculate_confusion_matrix(T_, P_, normalize=normalize, skip_tn=skip_tn,
+                                                       dtype=np.float64)
+                        key = f"C_{tname}_{pname}_skip{int(skip_tn)}_norm{int(normalize)}"
+                        out[key] = np.stack([C.tp, C.fp, C.fn, C.tn])
+        # dense
+        Yd = Y.toarray()
+        Pd = (Prand.toarray() > 0).astype(dtype)
+        Ld = L.toarray()
+        out["yd"], out["pd"], out["ld"] = Yd, Pd, Ld
+        for tname, T_ in (("yd", Yd), ("ld", Ld)):
+            for skip_tn in (False, True):
+                C = calculate_confusion_matrix(T_, Pd, normalize=False, skip_tn=skip_tn, dtype=np.float64)
+                out[f"C_{tname}_pd_skip{int(skip_tn)}_norm0"] = np.stack([C.tp, C.fp, C.fn, C.tn])
+        save("confusion_" + tag, **out)
+
+
+# ---------------------------------------------------------------------------
+# D. BCA on CSR
+# ---------------------------------------------------------------------------
+
+def run_bca(Y, spec):
+    """spec: dict(entry=..., k=..., kwargs=...) -> (y_pred, meta)."""
+    entry = spec["entry"]
+    kw = dict(spec.get("kwargs", {}))
+    if "init_matrix" in spec:
+        kw["init_y_pred"] = spec["init_matrix"]
+    if entry == "generic":
+        metric = getattr(ref_metrics, spec["metric"])
+        return ref_bc.predict_using_bc_with_0approx(Y, metric, spec["k"], return_meta=True, **kw)
+    fn = getattr(ref_bc, entry)
+    return fn(Y, spec["k"], return_meta=True, **kw)
+
+
+def spec_json(spec):
+    s = {k: v for k, v in spec.items() if k != "init_matrix"}
+    s["has_init_matrix"] = "init_matrix" in spec
+    return json.dumps(s, sort_keys=True)
+
+
+def gen_bca_csr():
+    # D1: the SURVEY section 8c anchor
+    rng = np.random.default_rng(0)
+    n, m, r, k = 2000, 300, 20, 5
+    cols = np.concatenate([np.sort(rng.choice(m, r, replace=False)) for _ in range(n)])
+    data = rng.random(n * r).astype(np.float32)
+    Y = csr_matrix((data, cols.astype(np.int32), (np.arange(n + 1) * r).astype(np.int32)), shape=(n, m))
+    spec = dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                kwargs=dict(seed=1, max_iters=5))
+    P, meta = run_bca(Y, spec)
+    assert abs(meta["utilities"][0] - 0.5711350158138998) < 1e-15, meta["utilities"]
+    out = {}
+    out.update(csr_fields("y", Y))
+    out.update(csr_fields("pred", P))
+    out["utilities"] = np.asarray(meta["utilities"], dtype=np.float64)
+    out["iters"] = np.int64(meta["iters"])
+    out["spec"] = np.asarray(spec_json(spec))
+    save("bca_csr_anchor_f32", **out)
+
+    # D2: many metrics / options on smaller inputs
+    for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        rng = np.random.default_rng(401 if tag == "f32" else 402)
+        n, m, r, k = 600, 80, 12, 3
+        Yu = fixed_csr(rng, n, m, r, dtype, skew=True)
+        Yz = fixed_csr(rng, n, m, r, dtype, zipf=True, skew=True)
+        init = fixed_csr(rng, n, m, k, dtype)   # explicit initial prediction, partly outside the support
+        init.data[:] = 1
+        specs = {
+            "f1": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k, kwargs=dict(seed=13, max_iters=4)),
+            "f1_zipf": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k, kwargs=dict(seed=13, max_iters=4), data="z"),
+            "precision": dict(entry="predict_optimizing_macro_precision_using_bc", k=k, kwargs=dict(seed=2, max_iters=3)),
+            "recall": dict(entry="predict_optimizing_macro_recall_using_bc", k=k, kwargs=dict(seed=3, max_iters=3)),
+            "jaccard": dict(entry="predict_optimizing_macro_jaccard_score_using_bc", k=k, kwargs=dict(seed=4, max_iters=3)),
+            "balacc": dict(entry="predict_optimizing_macro_balanced_accuracy_using_bc", k=k, kwargs=dict(seed=5, max_iters=3)),
+            "hmean": dict(entry="predict_optimizing_macro_hmean_using_bc", k=k, kwargs=dict(seed=6, max_iters=3)),
+            "gmean": dict(entry="predict_optimizing_macro_gmean_using_bc", k=k, kwargs=dict(seed=7, max_iters=3), data="z"),
+            "inst_prec_top": dict(entry="predict_optimizing_instance_precision_using_bc", k=k,
+                                  kwargs=dict(seed=8, max_iters=3, init_y_pred="top")),
+            "inst_prec_random": dict(entry="predict_optimizing_instance_precision_using_bc", k=k,
+                                     kwargs=dict(seed=8, max_iters=3)),
+            "mixed_f1": dict(entry="predict_optimizing_mixed_instance_precision_and_macro_f1_score_using_bc", k=k,
+                             kwargs=dict(seed=9, max_iters=3, alpha=0.3)),
+            "mixed_balacc": dict(entry="predict_optimizing_mixed_instance_precision_and_macro_balanced_accuracy_using_bc",
+                                 k=k, kwargs=dict(seed=10, max_iters=3, alpha=0.7)),
+            "mixed_recall": dict(entry="predict_optimizing_mixed_instance_precision_and_macro_recall_using_bc", k=k,
+                                 kwargs=dict(seed=11, max_iters=3, alpha=0.5), data="z"),
+            "fbeta2": dict(entry="generic", metric="binary_fbeta_score_on_conf_matrix", k=k,
+                           kwargs=dict(seed=12, max_iters=3, skip_tn=True, metric_kwargs=dict(beta=2.0, epsilon=1e-7))),
+            "recall_min": dict(entry="generic", metric="binary_recall_on_conf_matrix", k=k,
+                               kwargs=dict(seed=14, max_iters=3, maximize=False, skip_tn=True)),
+            "f1_noshuffle": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                                 kwargs=dict(seed=15, max_iters=3, shuffle_order=False)),
+            "f1_greedy": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                              kwargs=dict(seed=16, max_iters=3, init_y_pred="greedy")),
+            "f1_random": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                              kwargs=dict(seed=17, max_iters=3, init_y_pred="random")),
+            "balacc_greedy": dict(entry="predict_optimizing_macro_balanced_accuracy_using_bc", k=k,
+                                  kwargs=dict(seed=18, max_iters=2, init_y_pred="greedy")),
+            "f1_initmat": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                               kwargs=dict(seed=19, max_iters=3), init_matrix=True),
+            "f1_sum_nonorm_tol": dict(entry="generic", metric="binary_f1_score_on_conf_matrix", k=k,
+                                      kwargs=dict(seed=20, max_iters=6, tolerance=1e-4, metric_aggregation="sum",
+                                                  skip_tn=True)),
+            "accuracy": dict(entry="generic", metric="binary_accuracy_on_conf_matrix", k=k,
+                             kwargs=dict(seed=21, max_iters=2)),
+        }
+        out = {}
+        out.update(csr_fields("yu", Yu))
+        out.update(csr_fields("yz", Yz))
+        out.update(csr_fields("init", init))
+        names = []
+        for name, spec in specs.items():
+            Yin = Yz if spec.get("data") == "z" else Yu
+            spec_run = dict(spec)
+            if spec.get("init_matrix"):
+                spec_run["init_matrix"] = init.copy()
+            else:
+                spec_run.pop("init_matrix", None)
+            P, meta = run_bca(Yin, spec_run)
+            assert P.dtype == dtype and (np.diff(P.indptr) == k).all()
+            out.update(csr_fields("pred_" + name, P))
+            out["utilities_" + name] = np.asarray(meta["utilities"], dtype=np.float64)
+            out["iters_" + name] = np.int64(meta["iters"])
+            out["spec_" + name] = np.asarray(spec_json(spec))
+            names.append(name)
+            print(f"  bca_csr_{tag}/{name}: iters={meta['iters']} utilities={meta['utilities']}")
+        out["names"] = np.asarray(names)
+        save("bca_csr_" + tag, **out)
+
+
+# ---------------------------------------------------------------------------
+# E. BCA on dense
+# ---------------------------------------------------------------------------
+
+def gen_bca_dense():
+    for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        rng = np.random.default_rng(501 if tag == "f32" else 502)
+        n, m, k = 250, 30, 3
+        Y = (rng.random((n, m)) ** 3).astype(dtype)
+        specs = {
+            "f1_top": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k, kwargs=dict(seed=31, max_iters=3)),
+            "f1_random": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                              kwargs=dict(seed=32, max_iters=3, init_y_pred="random")),
+            "f1_greedy": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=k,
+                              kwargs=dict(seed=33, max_iters=3, init_y_pred="greedy")),
+            "recall": dict(entry="predict_optimizing_macro_recall_using_bc", k=k, kwargs=dict(seed=34, max_iters=3)),
+            "balacc": dict(entry="predict_optimizing_macro_balanced_accuracy_using_bc", k=k,
+                           kwargs=dict(seed=35, max_iters=3)),
+            "gmean_greedy": dict(entry="predict_optimizing_macro_gmean_using_bc", k=k,
+                                 kwargs=dict(seed=36, max_iters=2, init_y_pred="greedy")),
+            "mixed_hmean": dict(entry="predict_optimizing_mixed_instance_precision_and_macro_hmean_using_bc", k=k,
+                                kwargs=dict(seed=37, max_iters=3, alpha=0.4)),
+            "f1_k0": dict(entry="predict_optimizing_macro_f1_score_using_bc", k=0,
+                          kwargs=dict(seed=38, max_iters=3, init_y_pred="random")),
+            "jaccard_k0_top": dict(entry="predict_optimizing_macro_jaccard_score_using_bc", k=0,
+                                   kwargs=dict(seed=39, max_iters=3)),
+        }
+        out = {"y": Y}
+        names = []
+        for name, spec in specs.items():
+            P, meta = run_bca(Y, spec)
+            assert P.dtype == dtype and P.shape == (n, m)
+            out["pred_" + name] = P
+            out["utilities_" + name] = np.asarray(meta["utilities"], dtype=np.float64)
+            out["iters_" + name] = np.int64(meta["iters"])
+            out["spec_" + name] = np.asarray(spec_json(spec))
+            names.append(name)
+            print(f"  bca_dense_{tag}/{name}: iters={meta['iters']} utilities={meta['utilities']}")
+        out["names"] = np.asarray(names)
+        save("bca_dense_" + tag, **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense"]
+    for w in which:
+        globals()["gen_" + w]()

@@ -1,0 +1,115 @@
+"""Pins the CPU oracle (oracle/) against fixtures generated from the reference
+itself (tests/golden/make_golden.py).  Bit-exact for index sets and for values
+the reference computes without reductions; utilities / confusion vectors must be
+bit-identical too because the oracle repeats the reference's operation order."""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+import _golden as G
+
+
+def _same_csr(a, b, data_exact=True):
+    assert a.shape == b.shape
+    assert np.array_equal(np.asarray(a.indptr, dtype=np.int64), np.asarray(b.indptr, dtype=np.int64))
+    nnz = int(b.indptr[-1])
+    assert np.array_equal(a.indices[:nnz], b.indices[:nnz])
+    if data_exact:
+        assert np.array_equal(a.data[:nnz], b.data[:nnz])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_topk_csr_golden(oref, tag):
+    z = G.load("topk_csr_" + tag)
+    Y = G.csr_from(z, "y")
+    k = int(z["k"])
+    a, b = z["a"], z["b"]
+    cases = {
+        "plain": dict(), "scores": dict(keep_scores=True), "ab": dict(a=a, b=b),
+        "ab_scores": dict(a=a, b=b, keep_scores=True), "a_only": dict(a=a), "b_only": dict(b=b),
+    }
+    for name, kw in cases.items():
+        P = oref.predict_weighted_per_instance(Y, k, **kw)
+        assert P.dtype == Y.dtype
+        _same_csr(P, G.csr_from(z, "pred_" + name))
+    th = float(z["th"])
+    _same_csr(oref.predict_weighted_per_instance(Y, 0, th=th, a=a, b=b), G.csr_from(z, "pred_k0_ab"))
+    _same_csr(oref.predict_weighted_per_instance(Y, 0, th=th), G.csr_from(z, "pred_k0_plain"))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_topk_dense_golden(oref, tag):
+    z = G.load("topk_dense_" + tag)
+    Y, k = z["y"], int(z["k"])
+    a, b, a32, b32 = z["a"], z["b"], z["a32"], z["b32"]
+    th = float(z["th"])
+    cases = {
+        "plain": dict(), "scores": dict(keep_scores=True), "ab": dict(a=a, b=b),
+        "ab_scores": dict(a=a, b=b, keep_scores=True), "ab32": dict(a=a32, b=b32),
+        "ab32_scores": dict(a=a32, b=b32, keep_scores=True),
+    }
+    for name, kw in cases.items():
+        P = oref.predict_weighted_per_instance(Y, k, **kw)
+        assert P.dtype == Y.dtype
+        assert np.array_equal(P, z["pred_" + name]), name
+    assert np.array_equal(oref.predict_weighted_per_instance(Y, 0, th=th, a=a, b=b), z["pred_k0_ab"])
+    assert np.array_equal(oref.predict_weighted_per_instance(Y, 0, th=th), z["pred_k0_plain"])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_confusion_golden(oref, tag):
+    z = G.load("confusion_" + tag)
+    mats = {n: G.csr_from(z, n) for n in ("y", "p", "prand", "l")}
+    for tname in ("y", "l"):
+        for pname in ("p", "prand"):
+            for skip_tn in (False, True):
+                for normalize in (False, True):
+                    C = oref.calculate_confusion_matrix(mats[tname], mats[pname], normalize=normalize,
+                                                        skip_tn=skip_tn)
+                    exp = z[f"C_{tname}_{pname}_skip{int(skip_tn)}_norm{int(normalize)}"]
+                    assert np.array_equal(np.stack(C), exp), (tname, pname, skip_tn, normalize)
+    for tname in ("yd", "ld"):
+        for skip_tn in (False, True):
+            C = oref.calculate_confusion_matrix(z[tname], z["pd"], skip_tn=skip_tn)
+            assert np.array_equal(np.stack(C), z[f"C_{tname}_pd_skip{int(skip_tn)}_norm0"])
+
+
+def test_bca_csr_anchor_golden(oref):
+    z = G.load("bca_csr_anchor_f32")
+    Y = G.csr_from(z, "y")
+    spec = G.spec_of(z)
+    P, meta = G.oracle_call_from_spec(oref, spec, Y)
+    assert meta["iters"] == int(z["iters"])
+    assert np.array_equal(np.asarray(meta["utilities"]), z["utilities"])
+    # the SURVEY section 8c anchor values, re-derived when the fixture was generated
+    assert meta["utilities"][0] == 0.5711350158138998
+    assert meta["utilities"][-1] == 0.5716832858107608
+    _same_csr(P, G.csr_from(z, "pred"))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_bca_csr_golden(oref, tag):
+    z = G.load("bca_csr_" + tag)
+    Yu, Yz, init = G.csr_from(z, "yu"), G.csr_from(z, "yz"), G.csr_from(z, "init")
+    for name in [str(s) for s in z["names"]]:
+        spec = G.spec_of(z, name)
+        Y = Yz if spec.get("data") == "z" else Yu
+        P, meta = G.oracle_call_from_spec(oref, spec, Y, init_matrix=init.copy())
+        assert meta["iters"] == int(z["iters_" + name]), name
+        assert np.array_equal(np.asarray(meta["utilities"]), z["utilities_" + name]), (
+            name, meta["utilities"], z["utilities_" + name])
+        _same_csr(P, G.csr_from(z, "pred_" + name))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_bca_dense_golden(oref, tag):
+    z = G.load("bca_dense_" + tag)
+    Y = z["y"]
+    for name in [str(s) for s in z["names"]]:
+        spec = G.spec_of(z, name)
+        P, meta = G.oracle_call_from_spec(oref, spec, Y)
+        assert meta["iters"] == int(z["iters_" + name]), name
+        assert np.array_equal(np.asarray(meta["utilities"]), z["utilities_" + name]), (
+            name, meta["utilities"], z["utilities_" + name])
+        assert P.dtype == Y.dtype
+        assert np.array_equal(P, z["pred_" + name]), name
