@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- BCA macro-F1 sweeps on synthetic sparse score matrices.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--zipf]
+
+One "step" = one BCA sweep (block_coordinate.py:448-463 of the reference) over
+the rank's rows PLUS the sweep-boundary work the reference does every
+iteration: the from-scratch recompute of the expected confusion statistics
+(:465-467; one all-reduce when N > 1), the utility (:469-476) and its transfer
+to the host for the stopping rule.  Inputs (CSR y_proba, the initial top-k
+prediction, and the visiting orders of all W+K sweeps, generated with the
+reference's own np.random.default_rng stream) are resident in HBM before the
+timed region.  Weak scaling: every rank holds the workload's n rows
+(global n = N x n); value = N * n * K / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+R_NNZ = 50   # stored entries per row (primary)
+K = 5
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_row_step(r: int, k: int) -> int:
+    """SURVEY.md section 8(d) B_step: indptr 4 + CSR row 8r + three float64 gathers 24r +
+    old prediction 4k + new prediction 4k."""
+    return 4 + 32 * r + 8 * k
+
+
+def cpu_baseline(Y, k, seed, budget_s=12.0):
+    """The oracle (oracle/, a C restatement of the reference's sequential sweep) timed
+    on ONE host core on a bounded sample of the same workload: whole sweeps over
+    the first rows of the same matrix until ~budget_s of CPU work."""
+    from oracle import ref as oracle_ref
+
+    n, m = Y.shape
+    n_s = min(n, 100_000)
+    Ys = Y[:n_s]
+    metric = oracle_ref.make_metric(oracle_ref.FBETA, k=float(k), m=float(m))
+    sweeps, t_total = 0, 0.0
+    it = 2
+    while t_total < budget_s and sweeps < 64:
+        t0 = time.perf_counter()
+        _, meta = oracle_ref.predict_using_bc_with_0approx(Ys, metric, k, skip_tn=True, seed=seed, max_iters=it,
+                                                            tolerance=-1.0)
+        t_total += time.perf_counter() - t0
+        sweeps += meta["iters"]
+    return {
+        "value": n_s * sweeps / t_total,
+        "unit": "rows/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sweeps} sequential sweeps over the first {n_s} rows of the same matrix "
+                  f"(incl. top-k init and per-sweep confusion recompute), {t_total:.1f} s, 1 thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2_100Kx30K")
+    ap.add_argument("--zipf", action="store_true", help="Zipf(1) label popularity instead of uniform")
+    ap.add_argument("--waves", type=int, default=0, help="wavefronts walking the order (0 = product default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from xcolumns_amd import _device as D
+    from xcolumns_amd import _lib
+    from xcolumns_amd.block_coordinate import BcaCsrEngine, default_bca_waves
+    from xcolumns_amd.distributed import TorchComm
+    from xcolumns_amd.metrics import MetricSpec
+    from xcolumns_amd.synthetic import WORKLOADS, make_csr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        comm = TorchComm()
+
+    n, m = WORKLOADS[args.workload]
+    seed = 20240001 + rank
+    Y = make_csr(n, m, R_NNZ, seed=seed, zipf=args.zipf, k=K)
+    dev = D.require_gpu()
+    csr = D.DeviceCSR.from_scipy(Y, dev)
+    spec = MetricSpec(base=_lib.XC_M_FBETA)  # macro-F1: binary_f1_score_on_conf_matrix, eps 1e-9
+    eng = BcaCsrEngine(csr, K, spec, spec, maximize=True, skip_tn=True, n_total=n * world, comm=comm)
+    n_u = n * world   # normalisation of the utility = global row count
+
+    # visiting orders of every sweep, the reference's RNG stream (seed 13), uploaded up front
+    total = args.warmup + args.steps
+    rng = np.random.default_rng(13 + rank)
+    order = np.arange(n)
+    orders = torch.empty((total, n), dtype=torch.int32, device=dev)
+    for s in range(total):
+        rng.shuffle(order)
+        orders[s] = torch.from_numpy(order.astype(np.int32)).to(dev)
+
+    n_waves = args.waves if args.waves > 0 else default_bca_waves(n)
+    eng.init_top()
+    eng.reset_state(greedy=False)
+    u0 = eng.recompute_utility_sum(n_u) / m
+
+    ev_pairs = []
+
+    def step(s, timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        eng.sweep(orders[s], n, n_waves, greedy=False)
+        if timed:
+            e1.record()
+            ev_pairs.append((e0, e1))
+        return eng.recompute_utility_sum(n_u) / m
+
+    utilities = []
+    for s in range(args.warmup):
+        step(s, False)
+    # the timed steps are sweeps 1..K of a fresh run: back to the top-k prediction
+    # (untimed), so the measured mix of changed / unchanged rows is a real run's
+    eng.init_top()
+    eng.recompute_utility_sum(n_u)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        utilities.append(step(s, True))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sweep_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+    avg_sweep_s = (sum(sweep_ms) / len(sweep_ms)) / 1e3 if sweep_ms else float("nan")
+
+    if rank == 0:
+        b_step = algorithmic_bytes_per_row_step(R_NNZ, K)
+        achieved = b_step * n / avg_sweep_s / 1e9
+        out = {
+            "metric": "BCA iterations/sec x instances (rows/s) at k=5",
+            "value": n * world * args.steps / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: CSR n={n} rows/GPU, m={m} labels, {R_NNZ} entries/row, "
+                            f"{'Zipf(1)' if args.zipf else 'uniform'} label popularity, BCA macro-F1 k={K}, "
+                            f"init top-k, skip_tn, float32 scores, float64 statistics",
+                "rows_per_gpu": n, "labels": m, "nnz_per_row": R_NNZ, "k": K,
+                "concurrent_wavefronts": n_waves,
+                "step": "sweep kernel + tp/fp recompute + (all-reduce) + utility + D2H",
+            },
+            "roofline": {
+                "kernel": "bca_sweep_csr_kernel<float,1>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_row": b_step,
+                "avg_kernel_ms": avg_sweep_s * 1e3,
+            },
+            "utility_first_last": [utilities[0], utilities[-1]],
+            "utility_top_k": u0,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Y, K, seed=13)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

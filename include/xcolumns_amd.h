@@ -1,0 +1,230 @@
+/*
+ * xcolumns_amd.h -- C ABI of libxcolumns_amd.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for xCOLUMNs' block-coordinate-ascent prediction path.
+ * The reference (mwydmuch/xCOLUMNs 0.0.3) has no FFI of its own: its native
+ * layer is the set of numba-JIT functions in xcolumns/numba_csr_functions.py,
+ * flat functions over raw (data, indices, indptr) arrays.  Every entry point
+ * below replaces one of those (or the numpy code of one dense branch) and cites
+ * it as  <file>:<lines>  relative to /root/reference/xcolumns/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch-ROCm storage) unless
+ *     its name ends in _host; the callee never allocates, frees or synchronises
+ *     (xc_utility_finish_host is the one blocking call);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - CSR index arrays are int32, column ids sorted ascending within a row and
+ *     distinct (the reference's merges need the same, numba_csr_functions.py:121);
+ *   - `dtype` is XC_F32 or XC_F64: the element type of y_proba / y_pred data;
+ *   - return value: 0 on success, a negative XC_ERR_* for argument errors, a
+ *     positive hipError_t for runtime failures; xc_last_error() gives the text.
+ *   - no torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef XCOLUMNS_AMD_H
+#define XCOLUMNS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XC_ABI_VERSION 1
+
+enum { XC_F32 = 0, XC_F64 = 1 };
+
+enum {
+    XC_OK = 0,
+    XC_ERR_BAD_ARG = -1,      /* NULL pointer, negative size, unknown enum        */
+    XC_ERR_K_RANGE = -2,      /* k outside 1..XC_MAX_K                            */
+    XC_ERR_ROW_TOO_LONG = -3, /* a row holds more than XC_MAX_ROW_NNZ entries     */
+    XC_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                         */
+};
+
+#define XC_MAX_K 64          /* budget per row handled by the wavefront top-k    */
+#define XC_MAX_ROW_NNZ 1024  /* 16 candidates per lane x 64 lanes                */
+
+/* Binary metric evaluated on device: xcolumns/metrics.py binary_*_on_conf_matrix.
+ * With `mixed` set the value is (1 - alpha) * tp / kf + alpha * base(...) / mf,
+ * the closures of block_coordinate.py:848-1045. */
+enum {
+    XC_M_PRECISION_AT_K = 0, /* metrics.py:497-513 */
+    XC_M_PRECISION = 1,      /* metrics.py:585-605 */
+    XC_M_RECALL = 2,         /* metrics.py:633-652 */
+    XC_M_FBETA = 3,          /* metrics.py:683-730 (F1 = beta 1) */
+    XC_M_JACCARD = 4,        /* metrics.py:778-797 */
+    XC_M_BALANCED_ACC = 5,   /* metrics.py:824-845 */
+    XC_M_GMEAN = 6,          /* metrics.py:873-894 */
+    XC_M_HMEAN = 7,          /* metrics.py:922-944 */
+    XC_M_ACCURACY = 8,       /* metrics.py:400-419 */
+    XC_M_COUNT = 9
+};
+
+typedef struct xc_metric {
+    int32_t base;   /* XC_M_* */
+    int32_t mixed;  /* 0 / 1 */
+    double epsilon;
+    double beta;
+    double kf;      /* the k of precision@k */
+    double alpha;
+    double mf;      /* number of labels, for the mixed utilities */
+} xc_metric;
+
+/* Per-label BCA statistics, one 32-byte record per label (see DESIGN.md "data
+ * layout"): {tp, fp, s, spare} as float64 where s = tp + fn is the column sum
+ * of y_proba over the rows counted so far.  fn and tn are derived:
+ *   fn = s - tp,  tn = n_counted - fp - s.
+ * One record = one 32-byte sector, so a candidate label costs one gather. */
+#define XC_STATE_STRIDE 4 /* doubles per label */
+
+/* ---- library / device -------------------------------------------------- */
+
+int xc_abi_version(void);
+const char *xc_last_error(void);
+/* cu_count, waves_per_cu (resident wave slots), and the gcn arch name copied
+ * into arch[arch_len].  XC_ERR_NO_DEVICE when no HIP device is usable. */
+int xc_device_info(int *cu_count, int *waves_per_cu, char *arch, int arch_len);
+
+/* ---- weighted per-instance top-k -------------------------------------- */
+
+/* numba_predict_weighted_per_instance_csr, k > 0 (numba_csr_functions.py:585-629):
+ * gains = data (* a[col]) (+ b[col]) in `dtype`, multiply then add, never fused;
+ * top-k per row, ties to the lower column id; out_indices[n*k] ascending within
+ * a row; a row with fewer than k entries keeps all of them followed by the
+ * reference's padding (column 0, value 1).  out_data[n*k] receives 1 (or the
+ * gain when keep_scores).  out_eta (optional, n*k, `dtype`) receives the
+ * y_proba value of each chosen entry (0 for padding) -- the BCA driver keeps it
+ * next to the prediction.  a, b: optional, length m, already of `dtype`.
+ * max_row_nnz: longest row (<= XC_MAX_ROW_NNZ); it selects how many candidates a
+ * lane keeps in registers. */
+int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices,
+                const void *data, int dtype, int max_row_nnz, int k, const void *a,
+                const void *b, int keep_scores, int32_t *out_indices, void *out_data,
+                void *out_eta, void *stream);
+
+/* k == 0 branch (numba_csr_functions.py:631-653, :516-517): a row keeps the
+ * entries whose gain >= th.  Two calls: count -> (caller does the exclusive
+ * scan into out_indptr) -> fill. */
+int xc_threshold_count_csr(int64_t n, const int32_t *indptr, const int32_t *indices,
+                           const void *data, int dtype, double th, const void *a,
+                           const void *b, int32_t *out_counts, void *stream);
+int xc_threshold_fill_csr(int64_t n, const int32_t *indptr, const int32_t *indices,
+                          const void *data, int dtype, double th, const void *a,
+                          const void *b, const int32_t *out_indptr,
+                          int32_t *out_indices, void *stream);
+
+/* _predict_weighted_per_instance_dense (weighted_prediction.py:25-60).
+ * gains[n x m] (row stride ld elements) are ALREADY y_proba*a+b in the promoted
+ * dtype `gdtype` (the host forms them with the framework's own promotion rules);
+ * y_pred[n x m] (`pdtype`, contiguous) is overwritten: 0 everywhere, 1 (or the
+ * gain) at the k best columns of each row, ties to the lower column;
+ * k == 0: 1 where gain >= th. */
+int xc_topk_dense(int64_t n, int64_t m, int64_t ld, const void *gains, int gdtype,
+                  int k, double th, int keep_scores, void *y_pred, int pdtype,
+                  void *stream);
+
+/* ---- confusion matrix ---------------------------------------------------- */
+
+/* calculate_confusion_matrix, CSR branch, axis 0 (confusion_matrix.py:364-399 ->
+ * numba_csr_functions.py:143-182, :216-258), the three passes fused into one:
+ *   tp[j] += p*t, fp[j] += p*(1-t) (p alone when t is absent), fn[j] += t*(1-p).
+ * tp/fp/fn: float64[m], ACCUMULATED into (zero them first).  y_pred rows may
+ * repeat a column id (the top-k padding); the reference's last-write-wins
+ * scatter is reproduced for that case. */
+int xc_confusion_csr(int64_t n, int64_t m, const int32_t *t_indptr,
+                     const int32_t *t_indices, const void *t_data,
+                     const int32_t *p_indptr, const int32_t *p_indices,
+                     const void *p_data, int dtype, double *tp, double *fp,
+                     double *fn, void *stream);
+
+/* dense branch (confusion_matrix.py:160-166, :187-202): products in `dtype`,
+ * column sums in float64.  y_true, y_pred: n x m contiguous. */
+int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_pred,
+                       int dtype, double *tp, double *fp, double *fn, void *stream);
+
+/* ---- block coordinate ascent, CSR ------------------------------------- */
+
+/* For a prediction given as column ids (pred_indices[n*k], k per row), look up
+ * each id in its row of y_proba: pred_eta[n*k] <- the stored value, or 0 when the
+ * row does not hold that column (the reference treats it as eta = 0,
+ * numba_csr_functions.py:200-203). */
+int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indices,
+                           const void *data, int dtype, const int32_t *pred_indices,
+                           int k, void *pred_eta, void *stream);
+
+/* state[j].s += column sums of y_proba over its nnz stored entries (one-off;
+ * state zeroed by the caller). */
+int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data,
+                      int dtype, double *state, void *stream);
+
+/* Expected tp / fp of the current prediction, from scratch:
+ *   acc[j*2+0] += eta, acc[j*2+1] += (1 - eta) for every predicted (row, j)
+ * -- the tp and fp passes of calculate_confusion_matrix(y_proba, y_pred)
+ * (block_coordinate.py:430-436, :465-467); fn follows from s.  acc: float64
+ * [m*2], accumulated into (zero first; all-reduce it across ranks when the rows
+ * are sharded). */
+int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices,
+                           const void *pred_eta, int dtype, double *acc,
+                           void *stream);
+
+/* state[j].tp, state[j].fp <- acc[j] and, in the same pass, the per-label metric
+ * values of _calculate_utility (block_coordinate.py:54-90) on
+ * (tp/n, fp/n, fn/n, tn/n) with fn = s - tp and tn = n_counted - fp - s
+ * (tn = -1 when skip_tn, confusion_matrix.py:391-393), reduced to
+ * partials[XC_UTILITY_PARTIALS] in a fixed order.  acc may be NULL (evaluate the
+ * state as it stands). */
+#define XC_UTILITY_PARTIALS 1024
+int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted,
+                          const double *acc, double *state,
+                          const xc_metric *metric_host, int skip_tn,
+                          double *partials, void *stream);
+/* Blocking: waits for `stream`, sums the partials in index order on the host and
+ * writes the sum to *out_host (divide by m for "mean"). */
+int xc_utility_finish_host(const double *partials, double *out_host, void *stream);
+
+/* One sweep of block_coordinate.py:448-463 with _bc_with_0approx_step_csr
+ * (:212-293) as the body, for k > 0 and rows holding >= k entries.
+ *   order        int32[n_order] row ids in visiting order, or NULL for 0..n_order-1
+ *   n_norm       the divisor `n` of the step (:229-231)
+ *   pred_*       the prediction, updated in place
+ *   state        per-label records, updated with float64 atomics
+ *   greedy       first sweep of init_y_pred="greedy": rows are added as they are
+ *                visited (:243 skipped, stats start from zero)
+ *   n_waves      number of wavefronts that walk `order` concurrently: wave w takes
+ *                positions w, w + n_waves, ...  1 = the reference's exact
+ *                sequential sweep; larger values bound how many rows see
+ *                statistics that miss each other's update (DESIGN.md "staleness")
+ *   changed      optional int64[1], += number of rows whose prediction changed */
+int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
+                     const int32_t *indptr, const int32_t *indices, const void *data,
+                     int dtype, int max_row_nnz, int32_t *pred_indices,
+                     void *pred_eta, int k, double *state,
+                     const xc_metric *metric_host, int maximize, int greedy,
+                     int skip_tn, int n_waves, int64_t *changed, void *stream);
+
+/* Unpack the per-label records into the reference's four vectors
+ * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */
+int xc_bca_state_unpack(int64_t m, const double *state, double n_counted, int skip_tn,
+                        double *tp, double *fp, double *fn, double *tn, void *stream);
+
+/* ---- block coordinate ascent, dense ------------------------------------ */
+
+/* One sweep of block_coordinate.py:448-463 with _bc_with_0approx_step_dense
+ * (:132-209): y_proba, y_pred n x m contiguous of `dtype`; y_pred updated in
+ * place; k == 0 predicts every label with non-negative gain (:199-200).
+ * stats: float64[4*m] as four vectors tp | fp | fn | tn, updated in place.
+ * workspace: float64[m] scratch.  Rows are visited strictly in `order` (one
+ * workgroup walks them), m <= 65536. */
+int xc_bca_sweep_dense(int64_t n_order, const int32_t *order, int64_t n_norm,
+                       int64_t m, const void *y_proba, void *y_pred, int dtype, int k,
+                       double *stats, double *workspace, const xc_metric *metric_host,
+                       int maximize, int greedy, int skip_tn, void *stream);
+
+/* Utility of four plain vectors (dense path): partials as above. */
+int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
+                       const xc_metric *metric_host, double *partials, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XCOLUMNS_AMD_H */

@@ -41,6 +41,10 @@ static void FN(oracle_scatter)(double *dst, const int32_t *oi, const T *od,
  * returns how many were written (all `size` of them, in stored order, when
  * size <= k -- :465-466).
  * ------------------------------------------------------------------------ */
+/* NaN gains: np.argpartition(-g, k) sorts NaN last, i.e. a NaN gain is the
+ * least preferred; compare on a key that maps NaN to -inf. */
+static T FN(oracle_key)(T g) { return (g != g) ? (T)-INFINITY : g; }
+
 static int FN(oracle_topk_row)(const T *gains, const int32_t *ids, int size,
                                int k, int32_t *out_ids, T *out_vals)
 {
@@ -58,8 +62,10 @@ static int FN(oracle_topk_row)(const T *gains, const int32_t *ids, int size,
     for (int p = 0; p < size; ++p) {
         /* rank of p = number of entries that beat it */
         int rank = 0;
+        T kp = FN(oracle_key)(gains[p]);
         for (int q = 0; q < size; ++q) {
-            if (gains[q] > gains[p] || (gains[q] == gains[p] && q < p)) ++rank;
+            T kq = FN(oracle_key)(gains[q]);
+            if (kq > kp || (kq == kp && q < p)) ++rank;
         }
         if (rank < k) {
             out_ids[cnt] = ids[p];
@@ -149,8 +155,11 @@ void FN(oracle_topk_dense)(int64_t n, int64_t m, const T *gains, int k, T th,
         if (k > 0) {
             for (int64_t p = 0; p < m; ++p) {
                 int64_t rank = 0;
-                for (int64_t q = 0; q < m && rank < k; ++q)
-                    if (g[q] > g[p] || (g[q] == g[p] && q < p)) ++rank;
+                T kp = FN(oracle_key)(g[p]);
+                for (int64_t q = 0; q < m && rank < k; ++q) {
+                    T kq = FN(oracle_key)(g[q]);
+                    if (kq > kp || (kq == kp && q < p)) ++rank;
+                }
                 if (rank < k) o[p] = keep_scores ? g[p] : (T)1;
             }
         } else {
@@ -450,8 +459,12 @@ void FN(oracle_bca_sweep_dense)(int64_t n_norm, int64_t m, int64_t n_order,
         if (k > 0) { /* :193-198: k smallest negated gains */
             for (int64_t p = 0; p < m; ++p) {
                 int64_t rank = 0;
-                for (int64_t r = 0; r < m && rank < k; ++r)
-                    if (gains[r] < gains[p] || (gains[r] == gains[p] && r < p)) ++rank;
+                /* gains are negated here: NaN sorts last = key +inf */
+                double kp = (gains[p] != gains[p]) ? INFINITY : gains[p];
+                for (int64_t r = 0; r < m && rank < k; ++r) {
+                    double kr = (gains[r] != gains[r]) ? INFINITY : gains[r];
+                    if (kr < kp || (kr == kp && r < p)) ++rank;
+                }
                 if (rank < k) pred[p] = one;
             }
         } else { /* :199-200 */

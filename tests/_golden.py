@@ -93,3 +93,18 @@ def oracle_call_from_spec(oref, spec, y_proba, init_matrix=None):
     return oref.predict_using_bc_with_0approx(
         y_proba, metric, k, metric_aggregation=agg, maximize=maximize, skip_tn=skip_tn,
         init_y_pred=init, utility_metric=utility_metric, **kw)
+
+
+def product_call_from_spec(spec, y_proba, init_matrix=None, **extra):
+    """Run xcolumns_amd's entry point of the same name the reference's fixture used."""
+    import xcolumns_amd.block_coordinate as bc
+    import xcolumns_amd.metrics as pm
+
+    kw = dict(spec.get("kwargs", {}))
+    kw.update(extra)
+    if spec.get("has_init_matrix"):
+        kw["init_y_pred"] = init_matrix
+    if spec["entry"] == "generic":
+        return bc.predict_using_bc_with_0approx(y_proba, getattr(pm, spec["metric"]), spec["k"],
+                                                return_meta=True, **kw)
+    return getattr(bc, spec["entry"])(y_proba, spec["k"], return_meta=True, **kw)

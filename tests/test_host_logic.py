@@ -1,0 +1,143 @@
+"""CPU tests of the host-side logic around the kernels: metric resolution,
+argument validation (raised before any GPU work), RNG streams, wrappers'
+signatures, ConfusionMatrix arithmetic, sharding helpers."""
+import functools
+import inspect
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+from xcolumns_amd import _lib
+from xcolumns_amd import block_coordinate as bc
+from xcolumns_amd import metrics as pm
+from xcolumns_amd.confusion_matrix import ConfusionMatrix
+from xcolumns_amd.distributed import local_order, shard_bounds, shard_csr
+from xcolumns_amd.utils import random_at_k_csr, random_at_k_np
+
+
+def test_resolve_metric_known_and_unknown():
+    s = pm.resolve_metric(pm.binary_f1_score_on_conf_matrix)
+    assert s.base == _lib.XC_M_FBETA and s.beta == 1.0 and s.epsilon == 1e-9 and not s.mixed
+    s = pm.resolve_metric(pm.binary_fbeta_score_on_conf_matrix, {"beta": 2.0, "epsilon": 1e-7})
+    assert s.beta == 2.0 and s.epsilon == 1e-7
+    s = pm.resolve_metric(functools.partial(pm.binary_recall_on_conf_matrix, epsilon=1e-6))
+    assert s.base == _lib.XC_M_RECALL and s.epsilon == 1e-6
+    with pytest.raises(NotImplementedError):
+        pm.resolve_metric(lambda tp, fp, fn, tn: tp / (tp + fp + 1))
+    with pytest.raises(NotImplementedError):
+        pm.resolve_metric([pm.binary_recall_on_conf_matrix, pm.binary_precision_on_conf_matrix])
+    assert pm.resolve_metric([pm.binary_recall_on_conf_matrix] * 3).base == _lib.XC_M_RECALL
+    with pytest.raises(ValueError):
+        pm.resolve_metric(pm.binary_recall_on_conf_matrix, {"beta": 2.0})
+
+    # a function that merely shares the reference's name and lives in a module called `metrics`
+    def binary_jaccard_score_on_conf_matrix(tp, fp, fn, tn, epsilon=1e-9):
+        return tp / (tp + fp + fn + epsilon)
+
+    binary_jaccard_score_on_conf_matrix.__module__ = "xcolumns.metrics"
+    assert pm.resolve_metric(binary_jaccard_score_on_conf_matrix).base == _lib.XC_M_JACCARD
+
+
+def test_host_metric_formulas_match_oracle(oref):
+    rng = np.random.default_rng(3)
+    tp, fp, fn, tn = (rng.random(50) for _ in range(4))
+    table = [
+        (pm.binary_precision_on_conf_matrix, oref.PRECISION, {}), (pm.binary_recall_on_conf_matrix, oref.RECALL, {}),
+        (pm.binary_f1_score_on_conf_matrix, oref.FBETA, {}), (pm.binary_jaccard_score_on_conf_matrix, oref.JACCARD, {}),
+        (pm.binary_balanced_accuracy_on_conf_matrix, oref.BALANCED_ACC, {}), (pm.binary_gmean_on_conf_matrix, oref.GMEAN, {}),
+        (pm.binary_hmean_on_conf_matrix, oref.HMEAN, {}), (pm.binary_accuracy_on_conf_matrix, oref.ACCURACY, {}),
+    ]
+    for fn_, base, kw in table:
+        exp = oref.metric_values(oref.make_metric(base), tp, fp, fn, tn)
+        assert np.array_equal(fn_(tp, fp, fn, tn, **kw), exp), fn_.__name__
+        assert np.array_equal(pm.host_values(pm.resolve_metric(fn_), tp, fp, fn, tn), exp)
+    exp = oref.metric_values(oref.make_metric(oref.FBETA, beta=2.0, epsilon=1e-7), tp, fp, fn, tn)
+    assert np.array_equal(pm.binary_fbeta_score_on_conf_matrix(tp, fp, fn, tn, beta=2.0, epsilon=1e-7), exp)
+    mixed = pm.DeviceMetric(pm.MetricSpec(base=_lib.XC_M_FBETA, mixed=True, kf=3.0, alpha=0.3, mf=50.0),
+                            pm.binary_f1_score_on_conf_matrix, "mixed_utility_fn")
+    exp = oref.metric_values(oref.make_metric(oref.FBETA, k=3.0, mixed=True, alpha=0.3, m=50.0), tp, fp, fn, tn)
+    assert np.array_equal(mixed(tp, fp, fn, tn), exp)
+
+
+def test_validation_errors_before_gpu():
+    Y = csr_matrix(np.random.default_rng(0).random((6, 5)).astype(np.float32))
+    with pytest.raises(ValueError, match="k must be an integer"):
+        bc.predict_using_bc_with_0approx(Y, pm.binary_recall_on_conf_matrix, 2.5)
+    with pytest.raises(ValueError, match="y_proba must be"):
+        bc.predict_using_bc_with_0approx("nope", pm.binary_recall_on_conf_matrix, 2)
+    with pytest.raises(ValueError, match="aggregation"):
+        bc.predict_using_bc_with_0approx(Y, pm.binary_recall_on_conf_matrix, 2, metric_aggregation="max")
+    with pytest.raises(NotImplementedError):
+        bc.predict_using_bc_with_0approx(Y, lambda *a: a[0], 2)
+
+
+def test_wrapper_signatures_expose_kwargs():
+    """experiments/utils.py:16-26 filters kwargs through __signature__."""
+    sig = inspect.signature(bc.predict_optimizing_macro_f1_score_using_bc)
+    for name in ("tolerance", "init_y_pred", "max_iters", "shuffle_order", "return_meta", "seed", "verbose",
+                 "normalize_conf_matrix", "metric_kwargs"):
+        assert name in sig.parameters, name
+    for name in ("maximize", "skip_tn", "metric_aggregation"):
+        assert name not in sig.parameters
+    assert sig.parameters["tolerance"].default == 1e-6 and sig.parameters["max_iters"].default == 100
+    sig = inspect.signature(bc.predict_using_bc_with_0approx)
+    assert list(sig.parameters)[:3] == ["y_proba", "binary_metric_func", "k"]
+    assert sig.parameters["init_y_pred"].default == "top"
+    assert inspect.signature(bc.predict_optimizing_instance_precision_using_bc).parameters["init_y_pred"].default == "random"
+
+
+def test_order_stream_is_the_reference_stream():
+    """block_coordinate.py:413-419: one Generator, cumulative in-place shuffles."""
+    src = bc._OrderSource.__new__(bc._OrderSource)
+    src.n, src.shuffle, src.backend, src.dev = 10, True, "numpy", "cpu"
+    src.rng = np.random.default_rng(42)
+    src.order = np.arange(10)
+    src.gen = None
+    rng = np.random.default_rng(42)
+    ref = np.arange(10)
+    for _ in range(3):
+        rng.shuffle(ref)
+        got = src.next()
+        assert np.array_equal(got.numpy(), ref.astype(np.int32))
+
+
+def test_random_init_streams(oref):
+    a = random_at_k_np((20, 9), 3, dtype=np.float32, seed=5)
+    assert np.array_equal(a, oref.random_at_k_np((20, 9), 3, dtype=np.float32, seed=5))
+    assert (a.sum(axis=1) == 3).all()
+    c = random_at_k_csr((20, 9), 3, dtype=np.float32, seed=5)
+    co = oref.random_at_k_csr((20, 9), 3, dtype=np.float32, seed=5)
+    assert np.array_equal(c.indices, co.indices) and (np.diff(c.indptr) == 3).all()
+
+
+def test_confusion_matrix_class():
+    C = ConfusionMatrix(np.array([1.0, 2.0]), np.array([3.0, 4.0]), np.array([5.0, 6.0]), np.array([7.0, 8.0]))
+    tp, fp, fn, tn = C
+    assert tp[1] == 2.0 and tn[0] == 7.0
+    D2 = C + C
+    assert np.array_equal(D2.fp, [6.0, 8.0]) and C == ConfusionMatrix(*C)
+    assert (C * 2) == D2 and (D2 / 2) == C and (D2 - C) == C
+    N = C.normalize()
+    assert np.allclose(N.tp + N.fp + N.fn + N.tn, 1.0)
+    C += C
+    assert C == D2
+    assert ConfusionMatrix(1, 2, 3, 4) == ConfusionMatrix(1, 2, 3, 4) and ConfusionMatrix(1, 2, 3, 4) != 5
+
+
+def test_shard_helpers():
+    n, world = 103, 4
+    bounds = [shard_bounds(n, world, r) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n
+    assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+    assert max(b - a for a, b in bounds) - min(b - a for a, b in bounds) <= 1
+    rng = np.random.default_rng(1)
+    Y = csr_matrix((rng.random((n, 7)) > 0.5) * rng.random((n, 7)))
+    parts = [shard_csr(Y, world, r) for r in range(world)]
+    assert sum(p.nnz for p in parts) == Y.nnz
+    assert np.array_equal(np.vstack([p.toarray() for p in parts]), Y.toarray())
+    order = rng.permutation(n)
+    got = np.concatenate([local_order(order, *bounds[r]) + bounds[r][0] for r in range(world)])
+    assert sorted(got.tolist()) == list(range(n))
+    lo, hi = bounds[1]
+    assert np.array_equal(local_order(order, lo, hi) + lo, order[(order >= lo) & (order < hi)])

@@ -1,0 +1,570 @@
+"""Block coordinate ascent (BCA) prediction on MI355X.
+
+Drop-in for the generic-BCA part of /root/reference/xcolumns/block_coordinate.py:
+``predict_using_bc_with_0approx`` (:296-499), ``make_bc_wrapper`` and its products
+(:709-801), ``predict_optimizing_instance_precision_using_bc`` (:804-835) and the
+mixed-utility wrappers (:848-1045) -- same names, arguments, defaults, return
+types, ``meta`` keys and ValueErrors.  The Python ``for i in order`` loop of the
+reference (:448-463) and everything under it run in HIP kernels
+(csrc/xc_bca.hip, csrc/xc_dense.hip) behind the C ABI; this module keeps only
+the control flow around the sweeps: initial prediction, visiting order (the
+reference's own ``np.random.default_rng(seed)`` stream), utility trace and the
+stopping rule.
+
+Extra keyword arguments (all optional, swallowed by ``**kwargs`` in the
+reference's signature so call sites stay source-compatible):
+
+``bca_waves``      number of wavefronts that walk the visiting order concurrently
+                   (1 = the reference's exact sequential sweep; default: about
+                   ``n / XCOLUMNS_BCA_STALE_DIV`` capped by what the GPU holds).
+``order_backend``  "numpy" (default: the reference's RNG stream, generated on the
+                   host and uploaded) or "device" (``torch.randperm`` on the GPU,
+                   a different stream, no host work per sweep).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from time import time
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from scipy.sparse import csr_matrix
+
+from . import _device as D
+from . import _lib
+from .metrics import (
+    DeviceMetric,
+    MetricSpec,
+    binary_balanced_accuracy_on_conf_matrix,
+    binary_f1_score_on_conf_matrix,
+    binary_gmean_on_conf_matrix,
+    binary_hmean_on_conf_matrix,
+    binary_jaccard_score_on_conf_matrix,
+    binary_precision_at_k_on_conf_matrix,
+    binary_precision_on_conf_matrix,
+    binary_recall_on_conf_matrix,
+    resolve_metric,
+)
+from .types import DenseMatrix, Matrix, is_dense, is_matrix
+from .utils import add_kwargs_to_signature, log_info, log_warning, random_at_k_csr, random_at_k_np
+from .weighted_prediction import topk_csr_device, topk_dense_device
+
+# rows in flight against statistics that miss each other's update, as a
+# fraction of the rows: n_waves ~ n / STALE_DIV (DESIGN.md "staleness")
+_STALE_DIV = int(os.environ.get("XCOLUMNS_BCA_STALE_DIV", "64"))
+_MIN_WAVES = 64
+
+
+def default_bca_waves(n_order: int) -> int:
+    """How many wavefronts walk the visiting order concurrently by default."""
+    env = os.environ.get("XCOLUMNS_BCA_WAVES")
+    if env:
+        return max(1, int(env))
+    info = _lib.device_info()
+    cap = info["cu_count"] * info["waves_per_cu"]
+    want = max(_MIN_WAVES, n_order // max(1, _STALE_DIV))
+    return int(max(1, min(cap, want, n_order)))
+
+
+# ---------------------------------------------------------------------------
+# device-level engine (CSR)
+# ---------------------------------------------------------------------------
+
+class BcaCsrEngine:
+    """Device-resident state of one BCA run over CSR rows held by THIS rank.
+
+    HBM layout: CSR y_proba (int32 indptr/indices, f32|f64 data);
+    prediction as fixed-stride ``pred_idx[n*k]`` + ``pred_eta[n*k]``; per-label
+    records ``state[m][4] = {tp, fp, s, spare}`` float64; ``acc[m][2]`` float64 for
+    the from-scratch tp/fp of every sweep boundary (the all-reduce payload when
+    rows are sharded over ranks).
+    """
+
+    def __init__(self, csr: D.DeviceCSR, k: int, gain_spec: MetricSpec, utility_spec: MetricSpec,
+                 maximize: bool = True, skip_tn: bool = False, n_total: Optional[int] = None,
+                 comm=None):
+        if k < 1 or k > _lib.XC_MAX_K:
+            raise ValueError(f"k must be in 1..{_lib.XC_MAX_K} for sparse y_proba on the GPU, got {k}")
+        self.csr = csr
+        self.k = int(k)
+        self.gain_metric = gain_spec.to_c()
+        self.utility_metric = utility_spec.to_c()
+        self.maximize = bool(maximize)
+        self.skip_tn = bool(skip_tn)
+        self.n_total = int(csr.n if n_total is None else n_total)  # rows over all ranks
+        self.comm = comm
+        dev = csr.data.device
+        self.dev = dev
+        m = csr.m
+        self.state = torch.zeros((m, _lib.XC_STATE_STRIDE), dtype=torch.float64, device=dev)
+        self.acc = torch.zeros((m, 2), dtype=torch.float64, device=dev)
+        self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS, dtype=torch.float64, device=dev)
+        self.changed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.pred_idx: Optional[torch.Tensor] = None
+        self.pred_eta: Optional[torch.Tensor] = None
+
+    # -- initial prediction --------------------------------------------------
+    def init_top(self):
+        """predict_top_k (block_coordinate.py:40)."""
+        self.pred_idx, _, self.pred_eta = topk_csr_device(self.csr, self.k, want_eta=True)
+
+    def init_indices(self, pred_idx: torch.Tensor):
+        """An explicit prediction: k column ids per row."""
+        c = self.csr
+        self.pred_idx = pred_idx.to(device=self.dev, dtype=torch.int32).contiguous()
+        self.pred_eta = torch.empty(c.n * self.k, dtype=c.data.dtype, device=self.dev)
+        _lib.call("xc_bca_gather_pred_eta", c.n, D.ptr(c.indptr), D.ptr(c.indices), D.ptr(c.data), c.code,
+                  D.ptr(self.pred_idx), self.k, D.ptr(self.pred_eta), D.stream())
+
+    # -- statistics -------------------------------------------------------------
+    def reset_state(self, greedy: bool):
+        """Zero the records; unless `greedy`, s <- column sums of y_proba (all ranks)."""
+        self.state.zero_()
+        if not greedy:
+            c = self.csr
+            _lib.call("xc_bca_colsum_csr", c.nnz, D.ptr(c.indices), D.ptr(c.data), c.code,
+                      D.ptr(self.state), D.stream())
+            if self.comm is not None:
+                self.comm.all_reduce(self.state)
+
+    def sync_column_sums(self):
+        """After a greedy sweep on sharded rows: s holds this rank's rows only."""
+        if self.comm is not None:
+            s = self.state[:, 2].contiguous()
+            self.comm.all_reduce(s)
+            self.state[:, 2] = s
+
+    def recompute_utility_sum(self, n_norm_utility: int) -> float:
+        """calculate_confusion_matrix(y_proba, y_pred) + _calculate_utility
+        (block_coordinate.py:430-445 / :465-476): tp, fp from scratch (one
+        all-reduce of 2m doubles when sharded), then the sum over labels of the
+        binary metric on the normalised entries.  Blocks on the result."""
+        self.acc.zero_()
+        _lib.call("xc_bca_accumulate_pred", self.csr.n * self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
+                  self.csr.code, D.ptr(self.acc), D.stream())
+        if self.comm is not None:
+            self.comm.all_reduce(self.acc)
+        return self.utility_sum(n_norm_utility, commit=True)
+
+    def utility_sum(self, n_norm_utility: int, commit: bool = False, n_counted: Optional[float] = None,
+                    skip_tn: Optional[bool] = None) -> float:
+        _lib.call("xc_bca_commit_utility", self.csr.m, int(n_norm_utility),
+                  float(self.n_total if n_counted is None else n_counted),
+                  D.ptr(self.acc) if commit else None, D.ptr(self.state), ctypes.byref(self.utility_metric),
+                  int(self.skip_tn if skip_tn is None else skip_tn), D.ptr(self.partials), D.stream())
+        out = ctypes.c_double(0.0)
+        _lib.call("xc_utility_finish_host", D.ptr(self.partials), ctypes.byref(out), D.stream())
+        return out.value
+
+    # -- one sweep ------------------------------------------------------------------
+    def sweep(self, order: Optional[torch.Tensor], n_order: int, n_waves: int, greedy: bool = False):
+        """block_coordinate.py:448-463 over `order` (int32 row ids on the GPU, or
+        None for 0..n_order-1)."""
+        c = self.csr
+        _lib.call("xc_bca_sweep_csr", int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
+                  D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx),
+                  D.ptr(self.pred_eta), self.k, D.ptr(self.state), ctypes.byref(self.gain_metric),
+                  int(self.maximize), int(bool(greedy)), int(self.skip_tn), int(n_waves),
+                  D.ptr(self.changed), D.stream())
+
+    def confusion_vectors(self):
+        """(tp, fp, fn, tn) float64 tensors on the GPU, the reference's four vectors."""
+        m = self.csr.m
+        out = torch.empty((4, m), dtype=torch.float64, device=self.dev)
+        _lib.call("xc_bca_state_unpack", m, D.ptr(self.state), float(self.n_total), int(self.skip_tn),
+                  D.ptr(out[0]), D.ptr(out[1]), D.ptr(out[2]), D.ptr(out[3]), D.stream())
+        return out
+
+
+class _OrderSource:
+    """Visiting order per sweep (block_coordinate.py:413-419)."""
+
+    def __init__(self, n: int, seed, shuffle: bool, backend: str, dev):
+        self.n, self.shuffle, self.backend, self.dev = n, shuffle, backend, dev
+        if backend not in ("numpy", "device"):
+            raise ValueError("order_backend must be 'numpy' or 'device'")
+        self.rng = np.random.default_rng(seed)       # :413
+        self.order = np.arange(n)                     # :414, shuffled cumulatively
+        self.gen = None
+        if backend == "device" and shuffle:
+            self.gen = torch.Generator(device=dev)
+            self.gen.manual_seed(int(seed) if seed is not None else int(self.rng.integers(2 ** 31)))
+
+    def next(self) -> Optional[torch.Tensor]:
+        if not self.shuffle:
+            return None
+        if self.backend == "numpy":
+            self.rng.shuffle(self.order)              # :418-419
+            return torch.from_numpy(self.order.astype(np.int32)).to(self.dev, non_blocking=True)
+        return torch.randperm(self.n, generator=self.gen, device=self.dev, dtype=torch.int32)
+
+
+# ---------------------------------------------------------------------------
+# predict_using_bc_with_0approx
+# ---------------------------------------------------------------------------
+
+def _initial_csr_indices(y_proba: csr_matrix, init_y_pred, k: int, seed) -> Optional[np.ndarray]:
+    """block_coordinate.py:28-51 for CSR input; None means "top" (done on the GPU)."""
+    n, m = y_proba.shape
+    if isinstance(init_y_pred, str) and init_y_pred in ("random", "greedy"):
+        mat = random_at_k_csr((n, m), k, dtype=y_proba.dtype, seed=seed)
+        return mat.indices
+    if isinstance(init_y_pred, str) and init_y_pred == "top":
+        return None
+    if is_matrix(init_y_pred):
+        if init_y_pred.shape != (n, m):
+            raise ValueError(f"init_y_pred must have shape (n, m) = ({n}, {m}), but has shape {init_y_pred.shape}")
+        if not isinstance(init_y_pred, csr_matrix):
+            raise ValueError("init_y_pred must be a csr_matrix when y_proba is a csr_matrix")
+        if not (np.diff(init_y_pred.indptr) == k).all():
+            raise ValueError(
+                "on the GPU path init_y_pred must hold exactly k stored entries per row "
+                "(variable-length rows are not supported)")
+        return init_y_pred.indices
+    raise ValueError(
+        "init_y_pred must be np.ndarray, Torch.tensor, csr_matrix or str in ['random', 'greedy', 'top'], "
+        f"but has type {type(init_y_pred)}")
+
+
+def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
+            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves, order_backend):
+    n_rows, m = y_proba.shape
+    if k == 0:
+        raise NotImplementedError(
+            "k=0 (no budget) with sparse y_proba is not implemented on the GPU path yet; "
+            "pass a dense y_proba or k > 0")
+    row_nnz = np.diff(y_proba.indptr)
+    if n_rows > 0 and row_nnz.min() < k:
+        raise ValueError(
+            f"every row of a sparse y_proba must store at least k={k} entries on the GPU path "
+            f"(shortest row has {int(row_nnz.min())})")
+    dev = D.require_gpu()
+    csr = D.DeviceCSR.from_scipy(y_proba, dev)
+    eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn)
+
+    log_info("  Initializing initial prediction ...", verbose)
+    greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"
+    init_idx = _initial_csr_indices(y_proba, init_y_pred, k, seed)
+    if init_idx is None:
+        eng.init_top()
+    else:
+        eng.init_indices(torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)))
+
+    orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
+    n_waves = int(bca_waves) if bca_waves else default_bca_waves(n_u)
+    new_utility = None
+    for j in range(1, max_iters + 1):
+        log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
+        order = orders.next()
+        if j == 1:
+            eng.reset_state(greedy)
+        if greedy:
+            # all four vectors are zeros, tn included (:423-427)
+            old_utility = eng.utility_sum(n_u, n_counted=0.0, skip_tn=False)
+        elif new_utility is None:
+            log_info("    Calculating expected confusion matrix ...", verbose)
+            old_utility = eng.recompute_utility_sum(n_u)
+        else:
+            # the end-of-sweep recompute of sweep j-1 IS the start-of-sweep one of j (:430, :465)
+            old_utility = new_utility_sum
+        if metric_aggregation == "mean":
+            old_utility = old_utility / m
+
+        log_info("    Doing block coordinate optimization steps ...", verbose)
+        eng.sweep(order, n_u, n_waves, greedy=greedy)
+        if greedy:
+            eng.sync_column_sums()
+        new_utility_sum = eng.recompute_utility_sum(n_u)
+        new_utility = new_utility_sum / m if metric_aggregation == "mean" else new_utility_sum
+
+        greedy = False
+        meta["iters"] = j
+        meta["utilities"].append(new_utility)
+        log_info(f"    Iteration {j}/{max_iters} finished, expected metric value: {old_utility} -> {new_utility}", verbose)
+        if (maximize and new_utility - old_utility < tolerance) or (not maximize and new_utility - old_utility > tolerance):
+            log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
+            break
+
+    new_indices = eng.pred_idx.cpu().numpy()
+    if isinstance(init_y_pred, csr_matrix):
+        # the reference updates an explicit init_y_pred in place and returns it (:46, :285-287)
+        init_y_pred.indices[:] = new_indices.astype(init_y_pred.indices.dtype, copy=False)
+        return init_y_pred
+    out_indptr = (np.arange(n_rows + 1, dtype=np.int64) * k).astype(y_proba.indptr.dtype)
+    return csr_matrix((np.ones(n_rows * k, dtype=y_proba.dtype),
+                       new_indices.astype(y_proba.indices.dtype, copy=False), out_indptr), shape=(n_rows, m))
+
+
+def _dense_confusion(y: torch.Tensor, y_pred: torch.Tensor, stats: torch.Tensor, skip_tn: bool):
+    """calculate_confusion_matrix(y_proba, y_pred, normalize=False, skip_tn, float64)
+    into stats = tp | fp | fn | tn (block_coordinate.py:430-436)."""
+    n, m = y.shape
+    stats.zero_()
+    _lib.call("xc_confusion_dense", n, m, D.ptr(y), D.ptr(y_pred), D.dtype_code(y.dtype),
+              D.ptr(stats[0]), D.ptr(stats[1]), D.ptr(stats[2]), D.stream())
+    if skip_tn:
+        stats[3].fill_(-1.0)
+    else:
+        stats[3] = -stats[0] - stats[1] - stats[2] + float(n)   # confusion_matrix.py:397
+
+
+def _dense_utility(stats: torch.Tensor, n_u: int, metric_c, partials: torch.Tensor) -> float:
+    m = stats.shape[1]
+    _lib.call("xc_utility_vectors", m, int(n_u), D.ptr(stats), ctypes.byref(metric_c), D.ptr(partials), D.stream())
+    out = ctypes.c_double(0.0)
+    _lib.call("xc_utility_finish_host", D.ptr(partials), ctypes.byref(out), D.stream())
+    return out.value
+
+
+def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance, init_y_pred,
+              max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend):
+    n_rows, m = y_proba.shape
+    if k < 0:
+        raise ValueError("k must be >= 0")
+    dev = D.require_gpu()
+    is_torch = isinstance(y_proba, torch.Tensor)
+    y_host = y_proba if is_torch else torch.from_numpy(np.ascontiguousarray(y_proba))
+    D.dtype_code(y_host.dtype)
+    y = y_host.to(dev).contiguous()
+
+    log_info("  Initializing initial prediction ...", verbose)
+    greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"
+    init_is_matrix = False
+    if isinstance(init_y_pred, str) and init_y_pred in ("random", "greedy"):
+        y_pred = torch.from_numpy(random_at_k_np((n_rows, m), k, dtype=D.numpy_dtype(y.dtype), seed=seed)).to(dev)
+    elif isinstance(init_y_pred, str) and init_y_pred == "top":
+        y_pred = topk_dense_device(y, k, 0.0, False, y.dtype)
+    elif is_matrix(init_y_pred):
+        if tuple(init_y_pred.shape) != (n_rows, m):
+            raise ValueError(f"init_y_pred must have shape (n, m) = ({n_rows}, {m}), but has shape {init_y_pred.shape}")
+        if not is_dense(init_y_pred):
+            raise ValueError("init_y_pred must be dense when y_proba is dense")
+        init_is_matrix = True
+        src = init_y_pred if isinstance(init_y_pred, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(init_y_pred))
+        y_pred = src.to(device=dev, dtype=y.dtype).contiguous()
+    else:
+        raise ValueError(
+            "init_y_pred must be np.ndarray, Torch.tensor, csr_matrix or str in ['random', 'greedy', 'top'], "
+            f"but has type {type(init_y_pred)}")
+
+    gain_c, util_c = gain_spec.to_c(), utility_spec.to_c()
+    stats = torch.zeros((4, m), dtype=torch.float64, device=dev)
+    work = torch.empty(m, dtype=torch.float64, device=dev)
+    partials = torch.zeros(_lib.XC_UTILITY_PARTIALS, dtype=torch.float64, device=dev)
+    orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
+    for j in range(1, max_iters + 1):
+        log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
+        order = orders.next()
+        if greedy:
+            stats.zero_()                              # :423-427
+        else:
+            log_info("    Calculating expected confusion matrix ...", verbose)
+            _dense_confusion(y, y_pred, stats, skip_tn)
+        old_utility = _dense_utility(stats, n_u, util_c, partials)
+        if metric_aggregation == "mean":
+            old_utility /= m
+        log_info("    Doing block coordinate optimization steps ...", verbose)
+        _lib.call("xc_bca_sweep_dense", int(n_u), D.ptr(order), int(n_rows), int(m), D.ptr(y), D.ptr(y_pred),
+                  D.dtype_code(y.dtype), int(k), D.ptr(stats), D.ptr(work), ctypes.byref(gain_c), int(maximize),
+                  int(greedy), int(skip_tn), D.stream())
+        _dense_confusion(y, y_pred, stats, skip_tn)   # :465-467
+        new_utility = _dense_utility(stats, n_u, util_c, partials)
+        if metric_aggregation == "mean":
+            new_utility /= m
+        greedy = False
+        meta["iters"] = j
+        meta["utilities"].append(new_utility)
+        log_info(f"    Iteration {j}/{max_iters} finished, expected metric value: {old_utility} -> {new_utility}", verbose)
+        if (maximize and new_utility - old_utility < tolerance) or (not maximize and new_utility - old_utility > tolerance):
+            log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
+            break
+
+    if init_is_matrix:  # updated in place and returned (:46)
+        if isinstance(init_y_pred, torch.Tensor):
+            init_y_pred.copy_(y_pred.to(device=init_y_pred.device, dtype=init_y_pred.dtype))
+        else:
+            init_y_pred[...] = y_pred.cpu().numpy().astype(init_y_pred.dtype, copy=False)
+        return init_y_pred
+    if is_torch:
+        return y_pred.to(y_proba.device)
+    return y_pred.cpu().numpy()
+
+
+def predict_using_bc_with_0approx(
+    y_proba: Matrix,
+    binary_metric_func: Union[Callable, List[Callable]],
+    k: int,
+    metric_aggregation: str = "mean",  # "mean" or "sum"
+    normalize_conf_matrix: bool = True,
+    metric_kwargs: Optional[Dict[str, Any]] = None,
+    maximize: bool = True,
+    tolerance: float = 1e-6,
+    init_y_pred: Union[str, Matrix] = "top",  # "random", "top", "greedy", Matrix
+    max_iters: int = 100,
+    shuffle_order: bool = True,
+    skip_tn: bool = False,
+    return_meta: bool = False,
+    seed: Optional[int] = None,
+    verbose: bool = False,
+    **kwargs,
+) -> Union[Matrix, Tuple[Matrix, Dict[str, Any]]]:
+    r"""Block coordinate ascent / descent with the 0-th order approximation of the
+    expected-test-utility objective for a metric that decomposes over labels
+    (block_coordinate.py:296-499).
+
+    Sweeps over the rows of `y_proba`; for a row it takes the row's contribution
+    out of the expected per-label confusion statistics, scores every candidate
+    label by ``binary_metric(with the label predicted) - binary_metric(without)``,
+    keeps the `k` best and puts the contribution back.  Stops when a sweep
+    improves the utility by less than `tolerance` or after `max_iters` sweeps.
+
+    `binary_metric_func` must be one of the ``binary_*_on_conf_matrix`` metrics
+    (this package's or the reference's), a ``functools.partial`` of one, or a
+    :class:`~xcolumns_amd.metrics.DeviceMetric`; see
+    :func:`~xcolumns_amd.metrics.resolve_metric`.
+
+    Returns a matrix of the same type, shape and dtype as `y_proba`; with
+    `return_meta` also ``{"utilities": [...], "iters": int, "time": seconds}``.
+    """
+    log_info(
+        f"Starting optimization of ETU metric using block coordinate {'ascent (maximization)' if maximize else 'descent (minimization)'} algorithm ...",
+        verbose,
+    )
+    if isinstance(k, int) and k > 0:
+        log_info(f"  Budget k: {k}", verbose)
+    log_info(f"  Tolerance (stopping condition): {tolerance}, max iterations: {max_iters}", verbose)
+
+    meta: Dict[str, Any] = {"utilities": [], "iters": 0, "time": time()}
+
+    if not isinstance(k, int):
+        raise ValueError("k must be an integer")
+    if not (is_dense(y_proba) or isinstance(y_proba, csr_matrix)):
+        raise ValueError("y_proba must be either np.ndarray, torch.Tensor, or csr_matrix")
+    if metric_aggregation not in ("mean", "sum"):
+        raise ValueError(
+            f"Unsupported utility aggregation function: {metric_aggregation}, must be either 'mean' or 'sum'")
+
+    gain_spec = resolve_metric(binary_metric_func, metric_kwargs)
+    # _calculate_utility is called without metric_kwargs (:438-445, :469-476)
+    utility_spec = resolve_metric(binary_metric_func, None)
+
+    n, m = y_proba.shape
+    n_u = n if normalize_conf_matrix else 1   # :403-405 (also the length of the visiting order, :414)
+
+    bca_waves = kwargs.pop("bca_waves", None)
+    order_backend = kwargs.pop("order_backend", os.environ.get("XCOLUMNS_ORDER_BACKEND", "numpy"))
+
+    if isinstance(y_proba, csr_matrix):
+        y_pred = _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
+                         init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves,
+                         order_backend)
+    else:
+        y_pred = _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
+                           init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend)
+
+    if return_meta:
+        meta["time"] = time() - meta["time"]
+        return y_pred, meta
+    return y_pred
+
+
+# ---------------------------------------------------------------------------
+# wrappers for specific metrics (block_coordinate.py:709-801)
+# ---------------------------------------------------------------------------
+
+def make_bc_wrapper(binary_metric_func: Callable, metric_name: str, maximize: bool = True,
+                    metric_aggregation: str = "mean", skip_tn: bool = False, warn_k_eq_0: bool = False):
+    """Factory of ``f(y_proba, k, **kwargs)`` wrappers around
+    :func:`predict_using_bc_with_0approx` for one metric (block_coordinate.py:709-759)."""
+
+    def predict_optimizing_metric_using_bc(y_proba: Matrix, k: int, **kwargs):
+        if warn_k_eq_0 and k == 0:
+            log_warning(f"Warning: k=0 results in degenerated solution for {metric_name}!")
+        return predict_using_bc_with_0approx(y_proba, binary_metric_func, k, metric_aggregation=metric_aggregation,
+                                             maximize=maximize, skip_tn=skip_tn, **kwargs)
+
+    predict_optimizing_metric_using_bc.__doc__ = (
+        f"Predict optimizing {metric_name} with block coordinate ascent: "
+        f"``predict_using_bc_with_0approx(y_proba, {binary_metric_func.__name__}, k, "
+        f"metric_aggregation={metric_aggregation!r}, maximize={maximize}, skip_tn={skip_tn}, **kwargs)``."
+    )
+    return add_kwargs_to_signature(predict_optimizing_metric_using_bc, predict_using_bc_with_0approx,
+                                   skip=["metric_func", "metric_aggregation", "maximize", "skip_tn"])
+
+
+predict_optimizing_macro_precision_using_bc = make_bc_wrapper(
+    binary_precision_on_conf_matrix, "macro-averaged precision", metric_aggregation="mean", maximize=True,
+    skip_tn=True, warn_k_eq_0=True)
+predict_optimizing_macro_recall_using_bc = make_bc_wrapper(
+    binary_recall_on_conf_matrix, "macro-averaged recall", metric_aggregation="mean", maximize=True,
+    skip_tn=True, warn_k_eq_0=True)
+predict_optimizing_macro_f1_score_using_bc = make_bc_wrapper(
+    binary_f1_score_on_conf_matrix, "macro-averaged F1 score", metric_aggregation="mean", maximize=True,
+    skip_tn=True)
+predict_optimizing_macro_jaccard_score_using_bc = make_bc_wrapper(
+    binary_jaccard_score_on_conf_matrix, "macro-averaged Jaccard score", maximize=True, skip_tn=True)
+predict_optimizing_macro_balanced_accuracy_using_bc = make_bc_wrapper(
+    binary_balanced_accuracy_on_conf_matrix, "macro-averaged balanced accuracy", maximize=True)
+predict_optimizing_macro_hmean_using_bc = make_bc_wrapper(
+    binary_hmean_on_conf_matrix, "macro-averaged H-mean", maximize=True)
+predict_optimizing_macro_gmean_using_bc = make_bc_wrapper(
+    binary_gmean_on_conf_matrix, "macro-averaged G-mean", maximize=True)
+
+
+def predict_optimizing_instance_precision_using_bc(
+    y_proba,
+    k: int,
+    tolerance: float = 1e-6,
+    init_y_pred="random",
+    max_iters: int = 100,
+    shuffle_order: bool = True,
+    verbose: bool = False,
+    return_meta: bool = False,
+    **kwargs,
+):
+    """BCA with instance precision, tp / k summed over labels
+    (block_coordinate.py:804-835; note the "random" default initialisation)."""
+    metric = DeviceMetric(MetricSpec(base=_lib.XC_M_PRECISION_AT_K, kf=float(k) if k else 1.0),
+                          binary_precision_at_k_on_conf_matrix, "instance_precision_with_specific_k")
+    return predict_using_bc_with_0approx(
+        y_proba, binary_metric_func=metric, k=k, metric_aggregation="sum", tolerance=tolerance,
+        init_y_pred=init_y_pred, max_iters=max_iters, shuffle_order=shuffle_order, verbose=verbose,
+        return_meta=return_meta, **kwargs)
+
+
+# ---------------------------------------------------------------------------
+# mixed utilities (block_coordinate.py:848-1045):
+#   (1 - alpha) * tp / k + alpha * binary_metric(...) / m,  summed over labels
+# ---------------------------------------------------------------------------
+
+def _make_mixed_wrapper(base_id: int, host_base: Callable, what: str):
+    def predict_optimizing_mixed_using_bc(y_proba, k: int, alpha: float = 1, **kwargs):
+        n, m = y_proba.shape
+        metric = DeviceMetric(
+            MetricSpec(base=base_id, mixed=True, kf=float(k) if k else 1.0, alpha=float(alpha), mf=float(m)),
+            host_base, "mixed_utility_fn")
+        return predict_using_bc_with_0approx(y_proba, binary_metric_func=metric, k=k, metric_aggregation="sum",
+                                             skip_tn=True, **kwargs)
+
+    predict_optimizing_mixed_using_bc.__doc__ = (
+        f"BCA with a weighted average of instance precision and macro-averaged {what} "
+        "as the target: ``(1 - alpha) * precision@k + alpha * macro metric``.")
+    return predict_optimizing_mixed_using_bc
+
+
+predict_optimizing_mixed_instance_precision_and_macro_precision_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_PRECISION, binary_precision_on_conf_matrix, "precision")
+predict_optimizing_mixed_instance_precision_and_macro_recall_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_RECALL, binary_recall_on_conf_matrix, "recall")
+predict_optimizing_mixed_instance_precision_and_macro_f1_score_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_FBETA, binary_f1_score_on_conf_matrix, "F1 score")
+predict_optimizing_mixed_instance_precision_and_macro_balanced_accuracy_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_BALANCED_ACC, binary_balanced_accuracy_on_conf_matrix, "balanced accuracy")
+predict_optimizing_mixed_instance_precision_and_macro_jaccard_score_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_JACCARD, binary_jaccard_score_on_conf_matrix, "Jaccard score")
+predict_optimizing_mixed_instance_precision_and_macro_gmean_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_GMEAN, binary_gmean_on_conf_matrix, "G-mean")
+predict_optimizing_mixed_instance_precision_and_macro_hmean_using_bc = _make_mixed_wrapper(
+    _lib.XC_M_HMEAN, binary_hmean_on_conf_matrix, "H-mean")

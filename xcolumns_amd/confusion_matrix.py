@@ -1,0 +1,210 @@
+"""Per-label confusion statistics on MI355X.
+
+Same public surface as /root/reference/xcolumns/confusion_matrix.py:
+``ConfusionMatrix`` (:16-152), ``calculate_tp/fp/fn`` (:271-361) and
+``calculate_confusion_matrix`` (:364-399).  The column sums run in
+``xc_confusion_csr`` / ``xc_confusion_dense`` (csrc/xc_confusion.hip): one
+fused pass with float64 atomics instead of the reference's three merge passes.
+
+Divergences, all on purpose: sums are always accumulated in float64 and cast to
+`dtype` at the end (the reference accumulates in `dtype`, which defaults to
+y_true's); torch tensors are supported (the reference raises TypeError for
+them, SURVEY.md section 8 a-10 vi) and come back on the input's device.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import numpy as np
+import torch
+from scipy.sparse import csr_matrix
+
+from . import _device as D
+from . import _lib
+from .types import DenseMatrix, DType, Matrix, Number, is_dense
+
+
+class ConfusionMatrix:
+    """tp / fp / fn / tn (numbers or per-label vectors) with element-wise
+    arithmetic; unpacks as ``tp, fp, fn, tn`` so it can be splatted into the
+    ``*_on_conf_matrix`` metric functions."""
+
+    __slots__ = ("tp", "fp", "fn", "tn")
+
+    def __init__(self, tp, fp, fn, tn):
+        self.tp, self.fp, self.fn, self.tn = tp, fp, fn, tn
+
+    def _entries(self):
+        return (self.tp, self.fp, self.fn, self.tn)
+
+    def __iter__(self):
+        return iter(self._entries())
+
+    def __eq__(self, other: object) -> bool:
+        if not isinstance(other, ConfusionMatrix):
+            return False
+        for x, y in zip(self._entries(), other._entries()):
+            same = x == y
+            if not (bool(same) if isinstance(same, (bool, np.bool_)) else bool(same.all())):
+                return False
+        return True
+
+    def _map2(self, other, op) -> "ConfusionMatrix":
+        if isinstance(other, ConfusionMatrix):
+            return ConfusionMatrix(*(op(x, y) for x, y in zip(self._entries(), other._entries())))
+        return ConfusionMatrix(*(op(x, other) for x in self._entries()))
+
+    def _imap2(self, other, op) -> "ConfusionMatrix":
+        res = self._map2(other, op)
+        self.tp, self.fp, self.fn, self.tn = res.tp, res.fp, res.fn, res.tn
+        return self
+
+    def __add__(self, other):
+        return self._map2(other, lambda x, y: x + y)
+
+    def __iadd__(self, other):
+        return self._imap2(other, lambda x, y: x + y)
+
+    def __sub__(self, other):
+        return self._map2(other, lambda x, y: x - y)
+
+    def __isub__(self, other):
+        return self._imap2(other, lambda x, y: x - y)
+
+    def __mul__(self, other):
+        return self._map2(other, lambda x, y: x * y)
+
+    def __imul__(self, other):
+        return self._imap2(other, lambda x, y: x * y)
+
+    def __truediv__(self, other):
+        return self._map2(other, lambda x, y: x / y)
+
+    def __itruediv__(self, other):
+        return self._imap2(other, lambda x, y: x / y)
+
+    def __floordiv__(self, other):
+        return self._map2(other, lambda x, y: x // y)
+
+    def __ifloordiv__(self, other):
+        return self._imap2(other, lambda x, y: x // y)
+
+    def normalize(self) -> "ConfusionMatrix":
+        """Rates instead of counts: every entry divided by tp + fp + fn + tn."""
+        total = self.tp + self.fp + self.fn + self.tn
+        return ConfusionMatrix(self.tp / total, self.fp / total, self.fn / total, self.tn / total)
+
+
+# ---------------------------------------------------------------------------
+# device-level
+# ---------------------------------------------------------------------------
+
+def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR) -> torch.Tensor:
+    """tp | fp | fn as a (3, m) float64 tensor on the GPU."""
+    out = torch.zeros((3, t.m), dtype=torch.float64, device=t.data.device)
+    _lib.call("xc_confusion_csr", t.n, t.m, D.ptr(t.indptr), D.ptr(t.indices), D.ptr(t.data),
+              D.ptr(p.indptr), D.ptr(p.indices), D.ptr(p.data), t.code, D.ptr(out[0]), D.ptr(out[1]),
+              D.ptr(out[2]), D.stream())
+    return out
+
+
+def confusion_dense_device(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+    n, m = y_true.shape
+    out = torch.zeros((3, m), dtype=torch.float64, device=y_true.device)
+    _lib.call("xc_confusion_dense", n, m, D.ptr(y_true), D.ptr(y_pred), D.dtype_code(y_true.dtype),
+              D.ptr(out[0]), D.ptr(out[1]), D.ptr(out[2]), D.stream())
+    return out
+
+
+def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
+    """Validation of confusion_matrix.py:237-268, then the fused kernel.
+    Returns (tp, fp, fn) float64 torch tensors on the GPU, and a converter that
+    puts a result vector back where the inputs live."""
+    if is_dense(y_true) and is_dense(y_pred):
+        dense = True
+    elif isinstance(y_true, csr_matrix) and isinstance(y_pred, csr_matrix):
+        dense = False
+    else:
+        raise ValueError("y_true and y_pred must be both np.ndarray, both torch.Tensor, or csr_matrix")
+    if y_true.shape != y_pred.shape:
+        raise ValueError("y_true and y_pred must have the same shape")
+    if axis not in (0, 1):
+        raise ValueError("axis must be 0 or 1")
+    dev = D.require_gpu()
+    if dense:
+        is_torch = isinstance(y_true, torch.Tensor)
+        yt = y_true if is_torch else torch.from_numpy(np.ascontiguousarray(y_true))
+        if not yt.dtype.is_floating_point or yt.dtype not in (torch.float32, torch.float64):
+            yt = yt.to(torch.float64)
+        yp = y_pred if isinstance(y_pred, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_pred))
+        yt = yt.to(dev).contiguous()
+        yp = yp.to(device=dev, dtype=yt.dtype).contiguous()
+        if axis == 1:
+            yt, yp = yt.t().contiguous(), yp.t().contiguous()
+        stats = confusion_dense_device(yt, yp)
+        home = y_true.device if is_torch else None
+    else:
+        if axis == 1:
+            y_true, y_pred = y_true.T.tocsr(), y_pred.T.tocsr()
+            y_true.sort_indices()
+            y_pred.sort_indices()
+        if y_true.dtype not in (np.float32, np.float64):
+            y_true = y_true.astype(np.float64)
+        t = D.DeviceCSR.from_scipy(y_true, dev)
+        p = D.DeviceCSR.from_scipy(y_pred.astype(y_true.dtype, copy=False), dev)
+        stats = confusion_csr_device(t, p)
+        home = None
+        is_torch = False
+
+    def back(vec: torch.Tensor, dtype):
+        if is_torch:
+            v = vec.to(home)
+            return v.to(D.torch_dtype(dtype)) if dtype is not None else v.to(y_true.dtype)
+        out = vec.cpu().numpy()
+        return out.astype(dtype if dtype is not None else D.numpy_dtype(y_true.dtype), copy=False)
+
+    return stats, back
+
+
+def _single(which: int, y_true, y_pred, normalize, axis, dtype):
+    stats, back = _column_stats(y_true, y_pred, axis)
+    val = back(stats[which], dtype)
+    if normalize:  # confusion_matrix.py:265-266
+        val = val / y_true.shape[0]
+    return val
+
+
+def calculate_tp(y_true: Matrix, y_pred: Matrix, normalize: bool = False, axis: Optional[int] = 0,
+                 dtype: Optional[DType] = None):
+    """True positives along `axis` (confusion_matrix.py:271-299)."""
+    return _single(0, y_true, y_pred, normalize, axis, dtype)
+
+
+def calculate_fp(y_true: Matrix, y_pred: Matrix, normalize: bool = False, axis: Optional[int] = 0,
+                 dtype: Optional[DType] = None):
+    """False positives along `axis` (confusion_matrix.py:302-330)."""
+    return _single(1, y_true, y_pred, normalize, axis, dtype)
+
+
+def calculate_fn(y_true: Matrix, y_pred: Matrix, normalize: bool = False, axis: Optional[int] = 0,
+                 dtype: Optional[DType] = None):
+    """False negatives along `axis` (confusion_matrix.py:333-361)."""
+    return _single(2, y_true, y_pred, normalize, axis, dtype)
+
+
+def calculate_confusion_matrix(y_true: Matrix, y_pred: Matrix, normalize: bool = False, skip_tn: bool = False,
+                               axis: Optional[int] = 0, dtype: Optional[DType] = None) -> ConfusionMatrix:
+    """tp, fp, fn (one fused GPU pass) and tn derived from them
+    (confusion_matrix.py:364-399): tn = -1 when `skip_tn` (:391-393), else
+    ``-tp - fp - fn + (1 if normalize else n or m)`` (:397)."""
+    stats, back = _column_stats(y_true, y_pred, axis)
+    tp, fp, fn = (back(stats[i], dtype) for i in range(3))
+    n, m = y_true.shape
+    if normalize:
+        tp, fp, fn = tp / n, fp / n, fn / n
+    if skip_tn:
+        tn = tp.copy() if isinstance(tp, np.ndarray) else tp.clone()
+        tn[:] = -1
+    else:
+        tn = -tp - fp - fn + (1.0 if normalize else (n if axis == 0 else m))
+    return ConfusionMatrix(tp, fp, fn, tn)

@@ -1,0 +1,490 @@
+// xc_bca.hip -- block coordinate ascent on CSR rows (the dominant kernel).
+//
+// Replaces the row loop of predict_using_bc_with_0approx
+// (/root/reference/xcolumns/block_coordinate.py:448-463), its body
+// _bc_with_0approx_step_csr (:212-293) and the numba routines that body calls:
+// numba_sub_from_/add_to_unnormalized_confusion_matrix_csr
+// (numba_csr_functions.py:385-452) and numba_set_gains_csr (:499-546).
+//
+// Data layout.  Per label j one 32-byte record {tp, fp, s, spare} (float64),
+// s = tp + fn = column sum of y_proba over the rows counted so far.  One
+// candidate label = one 32-byte sector gathered from L2 / Infinity Cache
+// instead of three 8-byte gathers from three vectors.  fn = s - tp and
+// tn = n_counted - fp - s are derived in registers, so a change of prediction
+// touches only tp and fp (two adjacent float64 atomics = one 16-byte request).
+//
+// One wavefront per row.  "Remove the row's contribution" (:243-246) is done in
+// registers on the gathered values instead of by atomics on memory, and "add it
+// back" (:290-293) becomes atomics only for labels whose membership changed --
+// algebraically the same statistics, far fewer memory-side atomics.
+//
+// Sweep order and staleness.  The reference's loop is Gauss-Seidel: row i+1 sees
+// row i's update.  Here `n_waves` wavefronts walk the order array interleaved
+// (wave w takes positions w, w + n_waves, ...), all progressing at the same
+// pace, so a row misses at most the updates of the ~n_waves rows around it in
+// the order.  n_waves = 1 is the exact sequential sweep (used by the parity
+// tests); the driver picks n_waves as a small fraction of n.
+#include "xc_common.h"
+#include "xc_host.h"
+
+namespace xc {
+
+template <typename T>
+struct SweepParams {
+    int64_t n_order;
+    const int32_t *order;
+    const int32_t *indptr;
+    const int32_t *indices;
+    const T *data;
+    int32_t *pred_indices;
+    T *pred_eta;
+    int k;
+    double *state;
+    xc_metric metric;
+    double nn;        // divisor n of the step (block_coordinate.py:229-231)
+    double n_counted; // rows counted in the statistics when not greedy
+    int maximize;
+    int greedy;
+    int skip_tn;
+    int n_waves;
+    unsigned long long *changed;
+};
+
+template <typename T, int CH>
+__global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
+    const int lane = lane_id();
+    const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    if (wave >= P.n_waves) return;
+    const int k = P.k;
+    const double nn = P.nn;
+    const bool greedy = P.greedy != 0;
+    const bool skip_tn = P.skip_tn != 0;
+    unsigned long long n_changed = 0;
+
+    for (int64_t pos = wave; pos < P.n_order; pos += P.n_waves) {
+        const int64_t row = P.order ? (int64_t)P.order[pos] : pos;
+        const int s = P.indptr[row];
+        const int r = P.indptr[row + 1] - s;
+        int32_t *p_idx = P.pred_indices + row * k;
+        T *p_eta = P.pred_eta + row * k;
+
+        // current prediction of the row: lane q < k holds its q-th column id
+        const int old_id = (lane < k) ? p_idx[lane] : -1;
+
+        // candidates = the row's stored entries (the gains are only evaluated
+        // there: t_indices, block_coordinate.py:240, :248-250)
+        int idx[CH];
+        T eta[CH];
+        bool in_old[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = lane + XC_WAVE * c;
+            const bool valid = p < r;
+            idx[c] = valid ? P.indices[s + p] : -1;
+            eta[c] = valid ? P.data[s + p] : (T)0;
+            in_old[c] = false;
+        }
+
+        // membership of each candidate in the current prediction, and the
+        // predicted columns the row does not store ("orphans": eta = 0, they
+        // contributed fp += 1, numba_csr_functions.py:200-203) -- only foreign
+        // initial predictions have them; they leave the prediction for good here
+        if (!greedy) {
+            for (int q = 0; q < k; ++q) {
+                const int oid = __builtin_amdgcn_readlane(old_id, q);
+                bool hit_any = false;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const bool hit = (idx[c] == oid);
+                    in_old[c] = in_old[c] || hit;
+                    hit_any = hit_any || hit;
+                }
+                if (__ballot(hit_any) == 0ull && lane == 0)
+                    atomic_add_f64(P.state + (int64_t)oid * XC_STATE_STRIDE + 1, -1.0);
+            }
+        }
+
+        // gather the statistics of the candidate labels and form the gains
+        double gain[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = lane + XC_WAVE * c;
+            gain[c] = -INFINITY;
+            if (p < r) {
+                const double *st = P.state + (int64_t)idx[c] * XC_STATE_STRIDE;
+                double tp = load_coherent(st + 0);
+                double fp = load_coherent(st + 1);
+                double sc = greedy ? load_coherent(st + 2) : st[2];
+                const T e = eta[c];
+                const T om = (T)1 - e; // (1 - t_data) in the input dtype, :253
+                const double ed = (double)e;
+                const double omd = (double)om;
+                // statistics without this row (:243-246, done in registers)
+                if (in_old[c]) {
+                    tp -= ed;
+                    fp -= omd;
+                }
+                if (!greedy) sc -= ed;
+                const double fn = sc - tp;
+                // rows counted besides this one
+                const double n1 = greedy ? (double)pos : (P.n_counted - 1.0);
+                const double tn = n1 - fp - sc;
+                // :252-264
+                const double pos_tp = (tp + ed) / nn;
+                const double pos_fp = (fp + omd) / nn;
+                const double neg_fn = (fn + ed) / nn;
+                const double neg_tp = tp / nn;
+                const double neg_fp = fp / nn;
+                const double pos_fn = fn / nn;
+                // skip_tn: Etn is the constant -1, undivided (:260-261); all zeros in
+                // the greedy first sweep (:427)
+                double pos_tn = greedy ? 0.0 : -1.0, neg_tn = pos_tn;
+                if (!skip_tn) {
+                    neg_tn = (tn + omd) / nn;
+                    pos_tn = tn / nn;
+                }
+                // :267-282
+                double g = metric_eval(P.metric, pos_tp, pos_fp, pos_fn, pos_tn) -
+                           metric_eval(P.metric, neg_tp, neg_fp, neg_fn, neg_tn);
+                if (!P.maximize) g = -g;
+                gain[c] = nan_to_neg_inf(g);
+            }
+        }
+
+        // numba_set_gains_csr -> numba_argtopk_csr (numba_csr_functions.py:455-466,
+        // :514-524): k rounds of wavefront arg-max (rows hold >= k entries)
+        bool in_new[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) in_new[c] = false;
+        const int rounds = r < k ? r : k;
+        for (int round = 0; round < rounds; ++round) {
+            Best<double> b{-INFINITY, INT_MAX};
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int p = lane + XC_WAVE * c;
+                if (p < r && !in_new[c] && beats(gain[c], p, b.g, b.p)) {
+                    b.g = gain[c];
+                    b.p = p;
+                }
+            }
+            b = wave_argmax(b);
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (lane + XC_WAVE * c == b.p) in_new[c] = true;
+        }
+
+        // write the new prediction (ascending columns) and push the change of
+        // the statistics (:290-293 minus :243-246) to memory
+        int base = 0;
+        bool any_change = false;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = lane + XC_WAVE * c;
+            const unsigned long long mask = __ballot(in_new[c]);
+            if (in_new[c]) {
+                const int slot = base + __popcll(mask & lanemask_lt());
+                p_idx[slot] = idx[c];
+                p_eta[slot] = eta[c];
+            }
+            base += __popcll(mask);
+            if (p < r) {
+                double *st = P.state + (int64_t)idx[c] * XC_STATE_STRIDE;
+                const double ed = (double)eta[c];
+                const double omd = (double)((T)1 - eta[c]);
+                if (greedy) {
+                    atomic_add_f64(st + 2, ed);
+                    if (in_new[c]) {
+                        atomic_add_f64(st + 0, ed);
+                        atomic_add_f64(st + 1, omd);
+                    }
+                } else if (in_new[c] != in_old[c]) {
+                    any_change = true;
+                    const double sgn = in_new[c] ? 1.0 : -1.0;
+                    atomic_add_f64(st + 0, sgn * ed);
+                    atomic_add_f64(st + 1, sgn * omd);
+                }
+            }
+        }
+        if (__ballot(any_change) != 0ull) ++n_changed;
+
+        // exact mode: this wave's atomics must have been performed before it
+        // gathers statistics for its next row
+        if (P.n_waves == 1) __builtin_amdgcn_s_waitcnt(0);
+    }
+    if (P.changed && lane == 0 && n_changed)
+        atomicAdd(P.changed, n_changed);
+}
+
+// ---- pred_eta lookup --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(XC_BLOCK) void gather_pred_eta_kernel(
+    int64_t n_k, int k, const int32_t *indptr, const int32_t *indices, const T *data,
+    const int32_t *pred_indices, T *pred_eta) {
+    const int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
+    if (t >= n_k) return;
+    const int64_t row = t / k;
+    const int col = pred_indices[t];
+    int lo = indptr[row], hi = indptr[row + 1];
+    while (lo < hi) { // lower_bound
+        const int mid = (lo + hi) >> 1;
+        if (indices[mid] < col) lo = mid + 1;
+        else hi = mid;
+    }
+    T v = (T)0;
+    if (lo < indptr[row + 1] && indices[lo] == col) v = data[lo];
+    pred_eta[t] = v;
+}
+
+// ---- s = column sums of y_proba ------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(XC_BLOCK) void colsum_csr_kernel(int64_t nnz, const int32_t *indices,
+                                                              const T *data, double *state) {
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride)
+        atomic_add_f64(state + (int64_t)indices[t] * XC_STATE_STRIDE + 2, (double)data[t]);
+}
+
+// ---- tp / fp of the current prediction from scratch ------------------------------
+template <typename T>
+__global__ __launch_bounds__(XC_BLOCK) void accumulate_pred_kernel(int64_t n_k, const int32_t *pred_indices,
+                                                                   const T *pred_eta, double *acc) {
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < n_k; t += stride) {
+        const T e = pred_eta[t];
+        double *a = acc + (int64_t)pred_indices[t] * 2;
+        atomic_add_f64(a + 0, (double)e);            // pred * true
+        atomic_add_f64(a + 1, (double)((T)1 - e));   // pred * (1 - true), 1 when the row lacks the column
+    }
+}
+
+// ---- commit + utility ---------------------------------------------------------
+// Labels are split into XC_UTILITY_PARTIALS contiguous strips, one workgroup
+// each; the strip sum is a fixed-shape LDS tree, so the partials (and their
+// in-order host sum) do not depend on timing.
+__global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, double nn, double n_counted,
+                                                                  const double *acc, double *state,
+                                                                  xc_metric metric, int skip_tn,
+                                                                  double *partials) {
+    __shared__ double red[XC_BLOCK];
+    const int64_t per = (m + XC_UTILITY_PARTIALS - 1) / XC_UTILITY_PARTIALS;
+    const int64_t j0 = (int64_t)blockIdx.x * per;
+    const int64_t j1 = (j0 + per < m) ? j0 + per : m;
+    double sum = 0.0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += XC_BLOCK) {
+        double *st = state + j * XC_STATE_STRIDE;
+        double tp, fp;
+        if (acc) {
+            tp = acc[2 * j];
+            fp = acc[2 * j + 1];
+            st[0] = tp;
+            st[1] = fp;
+        } else {
+            tp = st[0];
+            fp = st[1];
+        }
+        const double sc = st[2];
+        const double fn = sc - tp;
+        // confusion_matrix.py:391-397; _calculate_utility gets Etn / n (:438-445)
+        const double tn = skip_tn ? -1.0 : (n_counted - fp - sc);
+        sum += metric_eval(metric, tp / nn, fp / nn, fn / nn, tn / nn);
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int w = XC_BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(XC_BLOCK) void utility_vectors_kernel(int64_t m, double nn, const double *stats,
+                                                                   xc_metric metric, double *partials) {
+    __shared__ double red[XC_BLOCK];
+    const int64_t per = (m + XC_UTILITY_PARTIALS - 1) / XC_UTILITY_PARTIALS;
+    const int64_t j0 = (int64_t)blockIdx.x * per;
+    const int64_t j1 = (j0 + per < m) ? j0 + per : m;
+    double sum = 0.0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += XC_BLOCK)
+        sum += metric_eval(metric, stats[j] / nn, stats[m + j] / nn, stats[2 * m + j] / nn, stats[3 * m + j] / nn);
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int w = XC_BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const double *state, double n_counted,
+                                                                int skip_tn, double *tp, double *fp, double *fn,
+                                                                double *tn) {
+    const int64_t j = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const double *st = state + j * XC_STATE_STRIDE;
+    tp[j] = st[0];
+    fp[j] = st[1];
+    fn[j] = st[2] - st[0];
+    tn[j] = skip_tn ? -1.0 : (n_counted - st[1] - st[2]);
+}
+
+template <typename T>
+static void launch_sweep(const SweepParams<T> &P, int ch, hipStream_t st) {
+    const int blocks = (P.n_waves + 3) / 4;
+    switch (ch) {
+    case 1: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 1>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 2>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 4>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 8>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    default: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 16>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    }
+}
+
+static int grid_for(int64_t n_items) {
+    int64_t b = (n_items + XC_BLOCK - 1) / XC_BLOCK;
+    const int64_t cap = 256 * 8 * 4; // grid-stride beyond a few blocks per CU
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+} // namespace xc
+
+extern "C" {
+
+int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
+                           int dtype, const int32_t *pred_indices, int k, void *pred_eta, void *stream) {
+    if (n < 0 || k < 1 || (n > 0 && (!indptr || !pred_indices || !pred_eta)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_gather_pred_eta: bad argument");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_gather_pred_eta: unknown dtype %d", dtype);
+    if (n == 0) return XC_OK;
+    const int64_t n_k = n * k;
+    const int blocks = (int)((n_k + XC_BLOCK - 1) / XC_BLOCK);
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32)
+        hipLaunchKernelGGL((xc::gather_pred_eta_kernel<float>), dim3(blocks), dim3(XC_BLOCK), 0, st, n_k, k, indptr, indices,
+                           static_cast<const float *>(data), pred_indices, static_cast<float *>(pred_eta));
+    else
+        hipLaunchKernelGGL((xc::gather_pred_eta_kernel<double>), dim3(blocks), dim3(XC_BLOCK), 0, st, n_k, k, indptr, indices,
+                           static_cast<const double *>(data), pred_indices, static_cast<double *>(pred_eta));
+    XC_CHECK_LAUNCH("gather_pred_eta_kernel");
+    return XC_OK;
+}
+
+int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data, int dtype, double *state,
+                      void *stream) {
+    if (nnz < 0 || (nnz > 0 && (!indices || !data || !state)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_colsum_csr: bad argument");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_colsum_csr: unknown dtype %d", dtype);
+    if (nnz == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    const int blocks = xc::grid_for(nnz);
+    if (dtype == XC_F32)
+        hipLaunchKernelGGL((xc::colsum_csr_kernel<float>), dim3(blocks), dim3(XC_BLOCK), 0, st, nnz, indices,
+                           static_cast<const float *>(data), state);
+    else
+        hipLaunchKernelGGL((xc::colsum_csr_kernel<double>), dim3(blocks), dim3(XC_BLOCK), 0, st, nnz, indices,
+                           static_cast<const double *>(data), state);
+    XC_CHECK_LAUNCH("colsum_csr_kernel");
+    return XC_OK;
+}
+
+int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices, const void *pred_eta, int dtype,
+                           double *acc, void *stream) {
+    if (n_k < 0 || (n_k > 0 && (!pred_indices || !pred_eta || !acc)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_accumulate_pred: bad argument");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_accumulate_pred: unknown dtype %d", dtype);
+    if (n_k == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    const int blocks = xc::grid_for(n_k);
+    if (dtype == XC_F32)
+        hipLaunchKernelGGL((xc::accumulate_pred_kernel<float>), dim3(blocks), dim3(XC_BLOCK), 0, st, n_k, pred_indices,
+                           static_cast<const float *>(pred_eta), acc);
+    else
+        hipLaunchKernelGGL((xc::accumulate_pred_kernel<double>), dim3(blocks), dim3(XC_BLOCK), 0, st, n_k, pred_indices,
+                           static_cast<const double *>(pred_eta), acc);
+    XC_CHECK_LAUNCH("accumulate_pred_kernel");
+    return XC_OK;
+}
+
+int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, const double *acc, double *state,
+                          const xc_metric *metric_host, int skip_tn, double *partials, void *stream) {
+    if (m < 0 || n_norm < 1 || !state || !metric_host || !partials)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: bad argument");
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: unknown metric %d", metric_host->base);
+    hipLaunchKernelGGL(xc::commit_utility_kernel, dim3(XC_UTILITY_PARTIALS), dim3(XC_BLOCK), 0, xc::as_stream(stream), m,
+                       (double)n_norm, n_counted, acc, state, *metric_host, skip_tn, partials);
+    XC_CHECK_LAUNCH("commit_utility_kernel");
+    return XC_OK;
+}
+
+int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats, const xc_metric *metric_host,
+                       double *partials, void *stream) {
+    if (m < 0 || n_norm < 1 || !stats || !metric_host || !partials)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_utility_vectors: bad argument");
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_utility_vectors: unknown metric %d", metric_host->base);
+    hipLaunchKernelGGL(xc::utility_vectors_kernel, dim3(XC_UTILITY_PARTIALS), dim3(XC_BLOCK), 0, xc::as_stream(stream), m,
+                       (double)n_norm, stats, *metric_host, partials);
+    XC_CHECK_LAUNCH("utility_vectors_kernel");
+    return XC_OK;
+}
+
+int xc_utility_finish_host(const double *partials, double *out_host, void *stream) {
+    if (!partials || !out_host) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_utility_finish_host: NULL pointer");
+    double buf[XC_UTILITY_PARTIALS];
+    hipStream_t st = xc::as_stream(stream);
+    XC_HIP_TRY(hipMemcpyAsync(buf, partials, sizeof(buf), hipMemcpyDeviceToHost, st));
+    XC_HIP_TRY(hipStreamSynchronize(st));
+    double sum = 0.0;
+    for (int i = 0; i < XC_UTILITY_PARTIALS; ++i) sum += buf[i];
+    *out_host = sum;
+    return XC_OK;
+}
+
+int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
+                     const int32_t *indices, const void *data, int dtype, int max_row_nnz,
+                     int32_t *pred_indices, void *pred_eta, int k, double *state,
+                     const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
+                     int64_t *changed, void *stream) {
+    if (n_order < 0 || n_norm < 1 || !indptr || !pred_indices || !pred_eta || !state || !metric_host)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
+    if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_sweep_csr: k=%d outside 1..%d", k, XC_MAX_K);
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: unknown dtype %d", dtype);
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: unknown metric %d", metric_host->base);
+    const int ch = xc::chunks_for(max_row_nnz);
+    if (ch == 0)
+        return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_bca_sweep_csr: a row holds %d entries, limit %d", max_row_nnz, XC_MAX_ROW_NNZ);
+    if (n_waves < 1) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: n_waves must be >= 1");
+    if (n_order == 0) return XC_OK;
+    if (n_waves > n_order) n_waves = (int)n_order;
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32) {
+        xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
+                                 static_cast<float *>(pred_eta), k, state, *metric_host, (double)n_norm,
+                                 (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                 reinterpret_cast<unsigned long long *>(changed)};
+        xc::launch_sweep<float>(P, ch, st);
+    } else {
+        xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
+                                  static_cast<double *>(pred_eta), k, state, *metric_host, (double)n_norm,
+                                  (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                  reinterpret_cast<unsigned long long *>(changed)};
+        xc::launch_sweep<double>(P, ch, st);
+    }
+    XC_CHECK_LAUNCH("bca_sweep_csr_kernel");
+    return XC_OK;
+}
+
+int xc_bca_state_unpack(int64_t m, const double *state, double n_counted, int skip_tn, double *tp, double *fp,
+                        double *fn, double *tn, void *stream) {
+    if (m < 0 || !state || !tp || !fp || !fn || !tn) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_state_unpack: bad argument");
+    if (m == 0) return XC_OK;
+    const int blocks = (int)((m + XC_BLOCK - 1) / XC_BLOCK);
+    hipLaunchKernelGGL(xc::state_unpack_kernel, dim3(blocks), dim3(XC_BLOCK), 0, xc::as_stream(stream), m, state, n_counted,
+                       skip_tn, tp, fp, fn, tn);
+    XC_CHECK_LAUNCH("state_unpack_kernel");
+    return XC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,121 @@
+// xc_common.h -- shared device helpers for libxcolumns_amd (gfx950 only).
+//
+// Wave = 64 lanes everywhere.  One wavefront owns one row of y_proba: lane l
+// holds candidates l, l + 64, ... (CH of them, compile-time), which keeps the
+// candidates of a sorted CSR row in ascending column order when read lane-major
+// chunk by chunk.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xcolumns_amd.h"
+
+#define XC_WAVE 64
+#define XC_BLOCK 256 /* 4 waves: one per SIMD of a CU */
+
+namespace xc {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (XC_WAVE - 1); }
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+// Statistics records are written by other waves' float64 atomics (performed at
+// the memory side of the XCD's L2), so they are read with agent-scope relaxed
+// atomic loads: `global_load_dwordx2 ... sc1`, which skips this CU's L1 (never
+// refreshed by other CUs' writes -- MI355X_MICROARCH "inter-workgroup
+// visibility").
+__device__ __forceinline__ double load_coherent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// No-return float64 add: one `global_atomic_add_f64`.
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- top-k selection key ---------------------------------------------------
+// Order: larger gain first; equal gains -> lower candidate position (= lower
+// column id in a sorted row); NaN gains last (numpy sorts NaN last in -gains).
+template <typename G>
+struct Best {
+    G g;
+    int p;
+};
+
+template <typename G>
+__device__ __forceinline__ G nan_to_neg_inf(G g) {
+    return (g != g) ? -INFINITY : g;
+}
+
+template <typename G>
+__device__ __forceinline__ bool beats(G g, int p, G og, int op) {
+    return (g > og) || (g == og && p < op);
+}
+
+template <typename G>
+__device__ __forceinline__ Best<G> wave_argmax(Best<G> b) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        G og = __shfl_xor(b.g, off, XC_WAVE);
+        int op = __shfl_xor(b.p, off, XC_WAVE);
+        if (beats(og, op, b.g, b.p)) {
+            b.g = og;
+            b.p = op;
+        }
+    }
+    return b; // identical in all lanes
+}
+
+// ---- binary metrics (xcolumns/metrics.py) ------------------------------------
+// Same operation order as the reference's numpy expressions; the translation
+// unit is compiled with -ffp-contract=off so no multiply is fused into an add.
+__device__ __forceinline__ double metric_base(const xc_metric &mt, double tp, double fp,
+                                              double fn, double tn) {
+    const double eps = mt.epsilon;
+    switch (mt.base) {
+    case XC_M_PRECISION_AT_K: // metrics.py:513
+        return tp / mt.kf;
+    case XC_M_PRECISION: // :605
+        return tp / (tp + fp + eps);
+    case XC_M_RECALL: // :652
+        return tp / (tp + fn + eps);
+    case XC_M_FBETA: { // :703
+        const double b2 = mt.beta * mt.beta;
+        return (1.0 + b2) * tp / ((b2 * (tp + fp)) + tp + fn + eps);
+    }
+    case XC_M_JACCARD: // :797
+        return tp / (tp + fp + fn + eps);
+    case XC_M_BALANCED_ACC: { // :843-845
+        const double tpr = tp / (tp + fn + eps);
+        const double tnr = tn / (tn + fp + eps);
+        return (tpr + tnr) / 2.0;
+    }
+    case XC_M_GMEAN: { // :892-894
+        const double tpr = tp / (tp + fn + eps);
+        const double tnr = tn / (tn + fp + eps);
+        return sqrt(tpr * tnr);
+    }
+    case XC_M_HMEAN: { // :942-944
+        const double tpr = tp / (tp + fn + eps);
+        const double tnr = tn / (tn + fp + eps);
+        return (2.0 * tpr * tnr) / (tpr + tnr);
+    }
+    case XC_M_ACCURACY: // :416-419
+        return (tp + tn) / (tp + fp + fn + tn);
+    default:
+        return __builtin_nan("");
+    }
+}
+
+__device__ __forceinline__ double metric_eval(const xc_metric &mt, double tp, double fp,
+                                              double fn, double tn) {
+    double v = metric_base(mt, tp, fp, fn, tn);
+    if (mt.mixed) // block_coordinate.py:862-865 and siblings
+        v = (1.0 - mt.alpha) * (tp / mt.kf) + mt.alpha * v / mt.mf;
+    return v;
+}
+
+} // namespace xc

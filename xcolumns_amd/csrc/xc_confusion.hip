@@ -1,0 +1,144 @@
+// xc_confusion.hip -- per-label confusion statistics (tp / fp / fn column sums).
+//
+// Replaces calculate_confusion_matrix's CSR and dense branches, axis 0
+// (/root/reference/xcolumns/confusion_matrix.py:364-399):
+//   CSR   -> numba_calculate_sum_csr_mat_mul_mat (numba_csr_functions.py:143-182)
+//            and numba_calculate_sum_csr_mat_mul_ones_minus_mat (:216-258),
+//            three passes there, ONE fused pass here;
+//   dense -> np.sum(y_true * y_pred, axis=0, dtype=float64) etc.
+//            (confusion_matrix.py:160-166, :187-202).
+// Column accumulation uses float64 global atomics (global_atomic_add_f64).
+#include "xc_common.h"
+#include "xc_host.h"
+
+namespace xc {
+
+// first position in [lo, hi) whose column is >= col
+__device__ __forceinline__ int lower_bound_col(const int32_t *indices, int lo, int hi, int col) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (indices[mid] < col) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// One wavefront per row; lanes stride over the row's y_pred entries and then
+// over its y_true entries, each locating its partner in the other (sorted) row
+// by binary search -- the rows are a few hundred bytes and stay in L1/L2.
+//
+// The reference's merges + `result[idx] += data` scatter give these rules when
+// a column id repeats in a y_pred row (the padding top-k leaves in short rows):
+//   tp: only the first of the repeats can match y_true (:128-139);
+//   fp: every repeat emits a value but the scatter keeps the last one, and only
+//       the first repeat is "matched" (:199-212, :254);
+//   fn: a y_true entry pairs with the first repeat (:199-212).
+template <typename T>
+__global__ __launch_bounds__(XC_BLOCK) void confusion_csr_kernel(
+    int64_t n, const int32_t *t_indptr, const int32_t *t_indices, const T *t_data,
+    const int32_t *p_indptr, const int32_t *p_indices, const T *p_data, double *tp, double *fp,
+    double *fn, int n_waves) {
+    const int lane = lane_id();
+    const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    if (wave >= n_waves) return;
+    for (int64_t row = wave; row < n; row += n_waves) {
+        const int ts = t_indptr[row], te = t_indptr[row + 1];
+        const int ps = p_indptr[row], pe = p_indptr[row + 1];
+        for (int q = ps + lane; q < pe; q += XC_WAVE) {
+            const int col = p_indices[q];
+            const T pv = p_data[q];
+            const bool first = (q == ps) || (p_indices[q - 1] != col);
+            const bool last = (q == pe - 1) || (p_indices[q + 1] != col);
+            const int t = lower_bound_col(t_indices, ts, te, col);
+            const bool found = first && t < te && t_indices[t] == col;
+            if (found) {
+                const T tv = t_data[t];
+                atomic_add_f64(tp + col, (double)(T)(pv * tv)); // :133
+                if (last) // a * (1.0 - b): float64 inside numba, stored as T (:197, :206)
+                    atomic_add_f64(fp + col, (double)(T)((double)pv * (1.0 - (double)tv)));
+            } else if (last) {
+                atomic_add_f64(fp + col, (double)pv); // :200-203
+            }
+        }
+        for (int t = ts + lane; t < te; t += XC_WAVE) {
+            const int col = t_indices[t];
+            const T tv = t_data[t];
+            const int q = lower_bound_col(p_indices, ps, pe, col);
+            T v = tv;
+            if (q < pe && p_indices[q] == col) v = (T)((double)tv * (1.0 - (double)p_data[q]));
+            if (v != (T)0) atomic_add_f64(fn + col, (double)v);
+        }
+    }
+}
+
+// Dense: a workgroup owns a strip of XC_BLOCK columns x ROWS_PER_BLOCK rows,
+// each thread sums its column over the strip's rows in row order (coalesced
+// row-major reads) and pushes one atomic per statistic.
+#define XC_CONF_ROWS_PER_BLOCK 256
+template <typename T>
+__global__ __launch_bounds__(XC_BLOCK) void confusion_dense_kernel(int64_t n, int64_t m, const T *y_true,
+                                                                   const T *y_pred, double *tp, double *fp,
+                                                                   double *fn) {
+    const int64_t j = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * XC_CONF_ROWS_PER_BLOCK;
+    const int64_t i1 = (i0 + XC_CONF_ROWS_PER_BLOCK < n) ? i0 + XC_CONF_ROWS_PER_BLOCK : n;
+    if (j >= m) return;
+    double stp = 0.0, sfp = 0.0, sfn = 0.0;
+    const T one = (T)1;
+    for (int64_t i = i0; i < i1; ++i) {
+        const T t = y_true[i * m + j];
+        const T p = y_pred[i * m + j];
+        stp += (double)(T)(t * p);          // confusion_matrix.py:166
+        sfp += (double)(T)((one - t) * p);  // :193
+        sfn += (double)(T)(t * (one - p));  // :202
+    }
+    if (stp != 0.0) atomic_add_f64(tp + j, stp);
+    if (sfp != 0.0) atomic_add_f64(fp + j, sfp);
+    if (sfn != 0.0) atomic_add_f64(fn + j, sfn);
+}
+
+} // namespace xc
+
+extern "C" {
+
+int xc_confusion_csr(int64_t n, int64_t m, const int32_t *t_indptr, const int32_t *t_indices,
+                     const void *t_data, const int32_t *p_indptr, const int32_t *p_indices,
+                     const void *p_data, int dtype, double *tp, double *fp, double *fn, void *stream) {
+    if (n < 0 || m < 0 || !t_indptr || !p_indptr || !tp || !fp || !fn)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr: NULL pointer or negative size");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr: unknown dtype %d", dtype);
+    if (n == 0) return XC_OK;
+    const int n_waves = xc::default_row_waves(n);
+    const int blocks = (n_waves + 3) / 4;
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32)
+        hipLaunchKernelGGL((xc::confusion_csr_kernel<float>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, t_indptr, t_indices,
+                           static_cast<const float *>(t_data), p_indptr, p_indices, static_cast<const float *>(p_data),
+                           tp, fp, fn, n_waves);
+    else
+        hipLaunchKernelGGL((xc::confusion_csr_kernel<double>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, t_indptr, t_indices,
+                           static_cast<const double *>(t_data), p_indptr, p_indices, static_cast<const double *>(p_data),
+                           tp, fp, fn, n_waves);
+    XC_CHECK_LAUNCH("confusion_csr_kernel");
+    return XC_OK;
+}
+
+int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_pred, int dtype, double *tp,
+                       double *fp, double *fn, void *stream) {
+    if (n < 0 || m < 0 || !tp || !fp || !fn || (n * m > 0 && (!y_true || !y_pred)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_dense: NULL pointer or negative size");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_dense: unknown dtype %d", dtype);
+    if (n == 0 || m == 0) return XC_OK;
+    dim3 grid((unsigned)((m + XC_BLOCK - 1) / XC_BLOCK), (unsigned)((n + XC_CONF_ROWS_PER_BLOCK - 1) / XC_CONF_ROWS_PER_BLOCK));
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32)
+        hipLaunchKernelGGL((xc::confusion_dense_kernel<float>), grid, dim3(XC_BLOCK), 0, st, n, m,
+                           static_cast<const float *>(y_true), static_cast<const float *>(y_pred), tp, fp, fn);
+    else
+        hipLaunchKernelGGL((xc::confusion_dense_kernel<double>), grid, dim3(XC_BLOCK), 0, st, n, m,
+                           static_cast<const double *>(y_true), static_cast<const double *>(y_pred), tp, fp, fn);
+    XC_CHECK_LAUNCH("confusion_dense_kernel");
+    return XC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,222 @@
+// xc_dense.hip -- dense-matrix branches of the path.
+//
+//   xc_topk_dense      <- _predict_weighted_per_instance_dense
+//                         (/root/reference/xcolumns/weighted_prediction.py:25-60)
+//   xc_bca_sweep_dense <- the row loop block_coordinate.py:448-463 with
+//                         _bc_with_0approx_step_dense (:132-209) as its body
+//
+// Dense rows touch all m labels, so there is no sparsity to exploit: top-k is
+// one workgroup per row streaming the row once (HBM-bound, 2 x sizeof per
+// element); the BCA sweep is inherently sequential in the rows (row i+1 reads
+// the statistics row i wrote for EVERY label), so one 1024-thread workgroup
+// walks the order array and parallelises over labels inside a row, keeping the
+// reference's exact operation order (bit-identical running statistics).
+#include "xc_common.h"
+#include "xc_host.h"
+
+namespace xc {
+
+// Workgroup-wide arg-best over (key, position); every thread returns the winner.
+// `smaller_first` orders by ascending key (used on negated gains), else descending.
+template <typename G, int BLOCK>
+__device__ __forceinline__ Best<G> block_argmax(Best<G> b, Best<G> *lds /* BLOCK/64 + 1 */) {
+    b = wave_argmax(b);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) lds[w] = b;
+    __syncthreads();
+    if (threadIdx.x < XC_WAVE) {
+        Best<G> v = (threadIdx.x < BLOCK / XC_WAVE) ? lds[threadIdx.x] : Best<G>{(G)-INFINITY, INT_MAX};
+        v = wave_argmax(v);
+        if (threadIdx.x == 0) lds[BLOCK / XC_WAVE] = v;
+    }
+    __syncthreads();
+    Best<G> r = lds[BLOCK / XC_WAVE];
+    __syncthreads();
+    return r;
+}
+
+// ---- dense top-k --------------------------------------------------------------
+// gains: G (promoted dtype), y_pred: P (y_proba's dtype).  Round t picks the best
+// element that is strictly worse than round t-1's winner in the total order
+// (gain desc, column asc), so no selected-set bookkeeping is needed.
+template <typename G, typename P>
+__global__ __launch_bounds__(XC_BLOCK) void topk_dense_kernel(int64_t m, int64_t ld, const G *gains, int k, G th,
+                                                              int keep_scores, P *y_pred) {
+    __shared__ Best<G> red[XC_BLOCK / XC_WAVE + 1];
+    const int64_t row = blockIdx.x;
+    const G *g = gains + row * ld;
+    P *o = y_pred + row * m;
+    if (k == 0) { // weighted_prediction.py:58
+        for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) o[j] = (g[j] >= th) ? (P)1 : (P)0;
+        return;
+    }
+    for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) o[j] = (P)0; // :35
+    Best<G> prev{(G)INFINITY, -1};
+    const int rounds = (int64_t)k < m ? k : (int)m;
+    for (int round = 0; round < rounds; ++round) {
+        Best<G> b{(G)-INFINITY, INT_MAX};
+        for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) {
+            const G key = nan_to_neg_inf(g[j]);
+            const int p = (int)j;
+            if (beats(prev.g, prev.p, key, p) && beats(key, p, b.g, b.p)) {
+                b.g = key;
+                b.p = p;
+            }
+        }
+        b = block_argmax<G, XC_BLOCK>(b, red);
+        if (threadIdx.x == 0) o[b.p] = keep_scores ? (P)g[b.p] : (P)1; // :47-49
+        prev = b;
+    }
+}
+
+// ---- dense BCA sweep -----------------------------------------------------------
+#define XC_DENSE_BLOCK 1024
+#define XC_DENSE_MAX_EPT 64 /* labels per thread tracked in the selection mask */
+
+template <typename T>
+struct DenseSweepParams {
+    int64_t n_order;
+    const int32_t *order;
+    int64_t m;
+    const T *y_proba;
+    T *y_pred;
+    int k;
+    double *tp, *fp, *fn, *tn;
+    double *gains; // workspace, m doubles
+    xc_metric metric;
+    double nn;
+    int maximize, greedy, skip_tn;
+};
+
+template <typename T>
+__global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_kernel(DenseSweepParams<T> P) {
+    __shared__ Best<double> red[XC_DENSE_BLOCK / XC_WAVE + 1];
+    const int64_t m = P.m;
+    const double nn = P.nn;
+    const T one = (T)1;
+    for (int64_t pos = 0; pos < P.n_order; ++pos) {
+        const int64_t row = P.order ? (int64_t)P.order[pos] : pos;
+        const T *eta = P.y_proba + row * m;
+        T *pred = P.y_pred + row * m;
+
+        for (int64_t j = threadIdx.x; j < m; j += XC_DENSE_BLOCK) {
+            const T t = eta[j];
+            const T p = pred[j];
+            const T om = one - t;
+            double tp = P.tp[j], fp = P.fp[j], fn = P.fn[j], tn = P.tn[j];
+            if (!P.greedy) { // block_coordinate.py:157-163
+                tp -= (double)(T)(p * t);
+                fp -= (double)(T)(p * om);
+                fn -= (double)(T)((one - p) * t);
+                if (!P.skip_tn) tn -= (double)(T)((one - p) * om);
+            }
+            // :166-185
+            const double pos_tp = tp + (double)t;
+            const double pos_fp = fp + (double)om;
+            const double neg_fn = fn + (double)t;
+            double neg_tn = tn;
+            if (!P.skip_tn) neg_tn = tn + (double)om;
+            double g = metric_eval(P.metric, pos_tp / nn, pos_fp / nn, fn / nn, tn / nn) -
+                       metric_eval(P.metric, tp / nn, fp / nn, neg_fn / nn, neg_tn / nn);
+            if (!P.maximize) g = -g;
+            P.tp[j] = tp; P.fp[j] = fp; P.fn[j] = fn; P.tn[j] = tn;
+            P.gains[j] = g; // larger is better here; the reference negates and takes the smallest (:187-198)
+            pred[j] = (T)0; // :191
+        }
+        __syncthreads();
+
+        unsigned long long mine = 0ull; // selected labels among this thread's (bit e <-> j = tid + e * BLOCK)
+        if (P.k > 0) {
+            Best<double> prev{INFINITY, -1};
+            const int rounds = (int64_t)P.k < m ? P.k : (int)m;
+            for (int round = 0; round < rounds; ++round) {
+                Best<double> b{-INFINITY, INT_MAX};
+                for (int64_t j = threadIdx.x; j < m; j += XC_DENSE_BLOCK) {
+                    const double key = nan_to_neg_inf(P.gains[j]);
+                    const int p = (int)j;
+                    if (beats(prev.g, prev.p, key, p) && beats(key, p, b.g, b.p)) {
+                        b.g = key;
+                        b.p = p;
+                    }
+                }
+                b = block_argmax<double, XC_DENSE_BLOCK>(b, red);
+                if ((b.p % XC_DENSE_BLOCK) == (int)threadIdx.x) mine |= 1ull << (b.p / XC_DENSE_BLOCK);
+                prev = b;
+            }
+        }
+
+        int e = 0;
+        for (int64_t j = threadIdx.x; j < m; j += XC_DENSE_BLOCK, ++e) {
+            bool sel;
+            if (P.k > 0) sel = (mine >> e) & 1ull;
+            else sel = (-P.gains[j]) <= 0.0; // :199-200 on the negated gains
+            const T t = eta[j];
+            const T p = sel ? one : (T)0;
+            const T om = one - t;
+            if (sel) pred[j] = one;
+            // :203-209
+            P.tp[j] += (double)(T)(p * t);
+            P.fp[j] += (double)(T)(p * om);
+            P.fn[j] += (double)(T)((one - p) * t);
+            if (!P.skip_tn) P.tn[j] += (double)(T)((one - p) * om);
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace xc
+
+extern "C" {
+
+int xc_topk_dense(int64_t n, int64_t m, int64_t ld, const void *gains, int gdtype, int k, double th,
+                  int keep_scores, void *y_pred, int pdtype, void *stream) {
+    if (n < 0 || m < 0 || ld < m || (n * m > 0 && (!gains || !y_pred)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_dense: NULL pointer or bad size");
+    if (k < 0) return xc::fail_arg(XC_ERR_K_RANGE, "xc_topk_dense: k=%d is negative", k);
+    if ((gdtype != XC_F32 && gdtype != XC_F64) || (pdtype != XC_F32 && pdtype != XC_F64))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_dense: unknown dtype");
+    if (m > (int64_t)INT32_MAX) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_dense: m too large");
+    if (n == 0 || m == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    dim3 grid((unsigned)n), block(XC_BLOCK);
+    if (gdtype == XC_F32 && pdtype == XC_F32)
+        hipLaunchKernelGGL((xc::topk_dense_kernel<float, float>), grid, block, 0, st, m, ld, static_cast<const float *>(gains), k, (float)th, keep_scores, static_cast<float *>(y_pred));
+    else if (gdtype == XC_F64 && pdtype == XC_F32)
+        hipLaunchKernelGGL((xc::topk_dense_kernel<double, float>), grid, block, 0, st, m, ld, static_cast<const double *>(gains), k, th, keep_scores, static_cast<float *>(y_pred));
+    else if (gdtype == XC_F32 && pdtype == XC_F64)
+        hipLaunchKernelGGL((xc::topk_dense_kernel<float, double>), grid, block, 0, st, m, ld, static_cast<const float *>(gains), k, (float)th, keep_scores, static_cast<double *>(y_pred));
+    else
+        hipLaunchKernelGGL((xc::topk_dense_kernel<double, double>), grid, block, 0, st, m, ld, static_cast<const double *>(gains), k, th, keep_scores, static_cast<double *>(y_pred));
+    XC_CHECK_LAUNCH("topk_dense_kernel");
+    return XC_OK;
+}
+
+int xc_bca_sweep_dense(int64_t n_order, const int32_t *order, int64_t n_norm, int64_t m, const void *y_proba,
+                       void *y_pred, int dtype, int k, double *stats, double *workspace,
+                       const xc_metric *metric_host, int maximize, int greedy, int skip_tn, void *stream) {
+    if (n_order < 0 || n_norm < 1 || m < 1 || !y_proba || !y_pred || !stats || !workspace || !metric_host)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_dense: NULL pointer or bad size");
+    if (k < 0) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_sweep_dense: k=%d is negative", k);
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_dense: unknown dtype %d", dtype);
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_dense: unknown metric %d", metric_host->base);
+    if (m > (int64_t)XC_DENSE_BLOCK * XC_DENSE_MAX_EPT)
+        return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_bca_sweep_dense: m=%lld exceeds %d", (long long)m, XC_DENSE_BLOCK * XC_DENSE_MAX_EPT);
+    if (n_order == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32) {
+        xc::DenseSweepParams<float> P{n_order, order, m, static_cast<const float *>(y_proba), static_cast<float *>(y_pred), k,
+                                      stats, stats + m, stats + 2 * m, stats + 3 * m, workspace, *metric_host,
+                                      (double)n_norm, maximize, greedy, skip_tn};
+        hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<float>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+    } else {
+        xc::DenseSweepParams<double> P{n_order, order, m, static_cast<const double *>(y_proba), static_cast<double *>(y_pred), k,
+                                       stats, stats + m, stats + 2 * m, stats + 3 * m, workspace, *metric_host,
+                                       (double)n_norm, maximize, greedy, skip_tn};
+        hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<double>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+    }
+    XC_CHECK_LAUNCH("bca_sweep_dense_kernel");
+    return XC_OK;
+}
+
+} // extern "C"

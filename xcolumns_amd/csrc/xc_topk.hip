@@ -1,0 +1,246 @@
+// xc_topk.hip -- weighted per-instance top-k on CSR rows.
+//
+// Replaces numba_predict_weighted_per_instance_csr
+// (/root/reference/xcolumns/numba_csr_functions.py:585-655) and the
+// numba_argtopk_csr / numba_topk_csr helpers it calls (:455-484).
+//
+// One wavefront per row.  The row's (column, value) pairs are read with
+// lane-contiguous 4-byte loads (a 50-entry row is two 200-byte segments), the
+// optional weights a[col], b[col] are gathered, the gain is formed in the input
+// dtype as multiply-then-add (never fused), and the k best are taken by k rounds
+// of a wavefront arg-max.  The winners are emitted in ascending column order by
+// a ballot/popcount compaction -- the row is sorted, so lane order is column
+// order.  HBM-bound: 8 B per stored entry in, 4 k (+ 2 x sizeof(T) k) B out.
+#include "xc_common.h"
+#include "xc_host.h"
+
+namespace xc {
+
+template <typename T>
+struct TopkParams {
+    int64_t n;
+    const int32_t *indptr;
+    const int32_t *indices;
+    const T *data;
+    const T *a;
+    const T *b;
+    int k;
+    int keep_scores;
+    int32_t *out_indices;
+    T *out_data;
+    T *out_eta;
+    int n_waves;
+};
+
+template <typename T, int CH>
+__global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
+    const int lane = lane_id();
+    const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    if (wave >= P.n_waves) return;
+    const int k = P.k;
+
+    for (int64_t row = wave; row < P.n; row += P.n_waves) {
+        const int s = P.indptr[row];
+        const int r = P.indptr[row + 1] - s;
+        int32_t *o_idx = P.out_indices + row * k;
+        T *o_dat = P.out_data + row * k;
+        T *o_eta = P.out_eta ? P.out_eta + row * k : nullptr;
+
+        int idx[CH];
+        T eta[CH];
+        T gain[CH];
+        bool sel[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = lane + XC_WAVE * c;
+            const bool valid = p < r;
+            idx[c] = valid ? P.indices[s + p] : -1;
+            eta[c] = valid ? P.data[s + p] : (T)0;
+            T g = eta[c];
+            if (valid && P.a) g = g * P.a[idx[c]]; // numba_csr_functions.py:608-609
+            if (valid && P.b) g = g + P.b[idx[c]]; // :610-611
+            gain[c] = g;
+            sel[c] = false;
+        }
+
+        int n_sel;
+        if (r <= k) {
+            // :465-466 / :483-484: all entries, stored order
+#pragma unroll
+            for (int c = 0; c < CH; ++c) sel[c] = (lane + XC_WAVE * c) < r;
+            n_sel = r;
+        } else {
+            for (int round = 0; round < k; ++round) {
+                Best<T> b{(T)-INFINITY, INT_MAX};
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int p = lane + XC_WAVE * c;
+                    if (p < r && !sel[c]) {
+                        const T key = nan_to_neg_inf(gain[c]);
+                        if (beats(key, p, b.g, b.p)) {
+                            b.g = key;
+                            b.p = p;
+                        }
+                    }
+                }
+                b = wave_argmax(b);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (lane + XC_WAVE * c == b.p) sel[c] = true;
+            }
+            n_sel = k;
+        }
+
+        // ascending-column emission
+        int base = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const unsigned long long mask = __ballot(sel[c]);
+            if (sel[c]) {
+                const int slot = base + __popcll(mask & lanemask_lt());
+                o_idx[slot] = idx[c];
+                o_dat[slot] = P.keep_scores ? gain[c] : (T)1;
+                if (o_eta) o_eta[slot] = eta[c];
+            }
+            base += __popcll(mask);
+        }
+        // :599-601: slots a short row leaves unused keep column 0 / value 1
+        if (lane >= n_sel && lane < k) {
+            o_idx[lane] = 0;
+            o_dat[lane] = (T)1;
+            if (o_eta) o_eta[lane] = (T)0;
+        }
+    }
+}
+
+// ---- k == 0: keep entries with gain >= th (numba_csr_functions.py:516-517) ----
+template <typename T, bool FILL>
+__global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
+    int64_t n, const int32_t *indptr, const int32_t *indices, const T *data, T th,
+    const T *a, const T *b, int32_t *out_counts, const int32_t *out_indptr,
+    int32_t *out_indices, int n_waves) {
+    const int lane = lane_id();
+    const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    if (wave >= n_waves) return;
+    for (int64_t row = wave; row < n; row += n_waves) {
+        const int s = indptr[row];
+        const int r = indptr[row + 1] - s;
+        int base = 0;
+        for (int p0 = 0; p0 < r; p0 += XC_WAVE) {
+            const int p = p0 + lane;
+            bool keep = false;
+            int col = -1;
+            if (p < r) {
+                col = indices[s + p];
+                T g = data[s + p];
+                if (a) g = g * a[col];
+                if (b) g = g + b[col];
+                keep = g >= th;
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (FILL && keep)
+                out_indices[out_indptr[row] + base + __popcll(mask & lanemask_lt())] = col;
+            base += __popcll(mask);
+        }
+        if (!FILL && lane == 0) out_counts[row] = base;
+    }
+}
+
+template <typename T>
+static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
+                       int k, const void *a, const void *b, int keep_scores, int32_t *out_indices,
+                       void *out_data, void *out_eta, int ch, hipStream_t st) {
+    TopkParams<T> P;
+    P.n = n;
+    P.indptr = indptr;
+    P.indices = indices;
+    P.data = static_cast<const T *>(data);
+    P.a = static_cast<const T *>(a);
+    P.b = static_cast<const T *>(b);
+    P.k = k;
+    P.keep_scores = keep_scores;
+    P.out_indices = out_indices;
+    P.out_data = static_cast<T *>(out_data);
+    P.out_eta = static_cast<T *>(out_eta);
+    P.n_waves = default_row_waves(n);
+    const int blocks = (P.n_waves + 3) / 4;
+    switch (ch) {
+    case 1: hipLaunchKernelGGL((topk_csr_kernel<T, 1>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((topk_csr_kernel<T, 2>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((topk_csr_kernel<T, 4>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((topk_csr_kernel<T, 8>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    default: hipLaunchKernelGGL((topk_csr_kernel<T, 16>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    }
+    return 0;
+}
+
+} // namespace xc
+
+extern "C" {
+
+int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data, int dtype,
+                int max_row_nnz, int k, const void *a, const void *b, int keep_scores,
+                int32_t *out_indices, void *out_data, void *out_eta, void *stream) {
+    if (n < 0 || !indptr || (n > 0 && (!out_indices || !out_data)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr: NULL pointer or negative n");
+    if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_topk_csr: k=%d outside 1..%d", k, XC_MAX_K);
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr: unknown dtype %d", dtype);
+    const int ch = xc::chunks_for(max_row_nnz);
+    if (ch == 0)
+        return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_topk_csr: a row holds %d entries, limit %d", max_row_nnz, XC_MAX_ROW_NNZ);
+    if (n == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32)
+        xc::launch_topk<float>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, ch, st);
+    else
+        xc::launch_topk<double>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, ch, st);
+    XC_CHECK_LAUNCH("topk_csr_kernel");
+    return XC_OK;
+}
+
+static int threshold_common(bool fill, int64_t n, const int32_t *indptr, const int32_t *indices,
+                            const void *data, int dtype, double th, const void *a, const void *b,
+                            int32_t *out_counts, const int32_t *out_indptr, int32_t *out_indices,
+                            void *stream) {
+    if (n < 0 || !indptr) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_csr: NULL pointer or negative n");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_csr: unknown dtype %d", dtype);
+    if (n == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    const int n_waves = xc::default_row_waves(n);
+    const int blocks = (n_waves + 3) / 4;
+    if (dtype == XC_F32) {
+        auto d = static_cast<const float *>(data);
+        auto aa = static_cast<const float *>(a);
+        auto bb = static_cast<const float *>(b);
+        if (fill)
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<float, true>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, (float)th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+        else
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<float, false>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, (float)th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+    } else {
+        auto d = static_cast<const double *>(data);
+        auto aa = static_cast<const double *>(a);
+        auto bb = static_cast<const double *>(b);
+        if (fill)
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<double, true>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+        else
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<double, false>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+    }
+    XC_CHECK_LAUNCH("threshold_csr_kernel");
+    return XC_OK;
+}
+
+int xc_threshold_count_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
+                           int dtype, double th, const void *a, const void *b, int32_t *out_counts,
+                           void *stream) {
+    if (n > 0 && !out_counts) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_count_csr: out_counts is NULL");
+    return threshold_common(false, n, indptr, indices, data, dtype, th, a, b, out_counts, nullptr, nullptr, stream);
+}
+
+int xc_threshold_fill_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
+                          int dtype, double th, const void *a, const void *b, const int32_t *out_indptr,
+                          int32_t *out_indices, void *stream) {
+    if (n > 0 && !out_indptr) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_fill_csr: out_indptr is NULL");
+    return threshold_common(true, n, indptr, indices, data, dtype, th, a, b, nullptr, out_indptr, out_indices, stream);
+}
+
+} // extern "C"

@@ -1,0 +1,235 @@
+"""Binary metrics on confusion-matrix entries and their device descriptors.
+
+The ``binary_*_on_conf_matrix`` functions keep the names, signatures and
+formulas of /root/reference/xcolumns/metrics.py (:400-419, :497-513, :585-605,
+:633-652, :683-730, :778-797, :824-845, :873-894, :922-944) and work on numbers,
+numpy arrays or torch tensors, so user code that evaluates them on the host
+keeps working.  Inside the BCA kernels the same formulas run on the GPU: an
+arbitrary Python callable cannot, so :func:`resolve_metric` maps a callable to a
+:class:`MetricSpec` (``struct xc_metric``) by identity / name and raises for
+anything it does not know -- the optimiser never silently optimises a different
+metric and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import functools
+from dataclasses import dataclass, replace
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class MetricSpec:
+    """Host mirror of ``struct xc_metric`` (include/xcolumns_amd.h)."""
+
+    base: int
+    mixed: bool = False
+    epsilon: float = 1e-9
+    beta: float = 1.0
+    kf: float = 1.0
+    alpha: float = 1.0
+    mf: float = 1.0
+
+    def to_c(self) -> _lib.XcMetric:
+        return _lib.XcMetric(int(self.base), int(self.mixed), float(self.epsilon), float(self.beta),
+                             float(self.kf), float(self.alpha), float(self.mf))
+
+    @property
+    def uses_tn(self) -> bool:
+        return self.base in (_lib.XC_M_BALANCED_ACC, _lib.XC_M_GMEAN, _lib.XC_M_HMEAN, _lib.XC_M_ACCURACY)
+
+
+def _tag(base: int):
+    def deco(fn):
+        fn._xc_base = base
+        return fn
+    return deco
+
+
+@_tag(_lib.XC_M_ACCURACY)
+def binary_accuracy_on_conf_matrix(tp, fp, fn, tn, normalize: bool = True):
+    r"""(TP + TN) / (TP + FP + FN + TN); the plain sum TP + TN when not normalised."""
+    acc = tp + tn
+    if normalize:
+        acc = acc / (tp + fp + fn + tn)
+    return acc
+
+
+@_tag(_lib.XC_M_PRECISION_AT_K)
+def binary_precision_at_k_on_conf_matrix(tp, fp, fn, tn, k: int):
+    r"""TP / k."""
+    return tp / k
+
+
+@_tag(_lib.XC_M_PRECISION)
+def binary_precision_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""TP / (TP + FP + eps)."""
+    return tp / (tp + fp + epsilon)
+
+
+@_tag(_lib.XC_M_RECALL)
+def binary_recall_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""TP / (TP + FN + eps)."""
+    return tp / (tp + fn + epsilon)
+
+
+@_tag(_lib.XC_M_FBETA)
+def binary_fbeta_score_on_conf_matrix(tp, fp, fn, tn, beta: float = 1.0, epsilon: float = 1e-9):
+    r"""(1 + beta^2) TP / (beta^2 (TP + FP) + TP + FN + eps)."""
+    return (1 + beta**2) * tp / ((beta**2 * (tp + fp)) + tp + fn + epsilon)
+
+
+@_tag(_lib.XC_M_FBETA)
+def binary_f1_score_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""F-beta with beta = 1."""
+    return binary_fbeta_score_on_conf_matrix(tp, fp, fn, tn, beta=1.0, epsilon=epsilon)
+
+
+@_tag(_lib.XC_M_JACCARD)
+def binary_jaccard_score_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""TP / (TP + FP + FN + eps)."""
+    return tp / (tp + fp + fn + epsilon)
+
+
+@_tag(_lib.XC_M_BALANCED_ACC)
+def binary_balanced_accuracy_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""(TPR + TNR) / 2 with TPR = TP / (TP + FN + eps), TNR = TN / (TN + FP + eps)."""
+    tpr = tp / (tp + fn + epsilon)
+    tnr = tn / (tn + fp + epsilon)
+    return (tpr + tnr) / 2
+
+
+@_tag(_lib.XC_M_GMEAN)
+def binary_gmean_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""sqrt(TPR * TNR)."""
+    tpr = tp / (tp + fn + epsilon)
+    tnr = tn / (tn + fp + epsilon)
+    return (tpr * tnr) ** 0.5
+
+
+@_tag(_lib.XC_M_HMEAN)
+def binary_hmean_on_conf_matrix(tp, fp, fn, tn, epsilon: float = 1e-9):
+    r"""2 TPR TNR / (TPR + TNR)."""
+    tpr = tp / (tp + fn + epsilon)
+    tnr = tn / (tn + fp + epsilon)
+    return (2 * tpr * tnr) / (tpr + tnr)
+
+
+# the reference's own functions, recognised by name when a caller passes them
+_BASE_BY_NAME = {
+    "binary_accuracy_on_conf_matrix": _lib.XC_M_ACCURACY,
+    "binary_precision_at_k_on_conf_matrix": _lib.XC_M_PRECISION_AT_K,
+    "binary_precision_on_conf_matrix": _lib.XC_M_PRECISION,
+    "binary_recall_on_conf_matrix": _lib.XC_M_RECALL,
+    "binary_fbeta_score_on_conf_matrix": _lib.XC_M_FBETA,
+    "binary_f1_score_on_conf_matrix": _lib.XC_M_FBETA,
+    "binary_jaccard_score_on_conf_matrix": _lib.XC_M_JACCARD,
+    "binary_balanced_accuracy_on_conf_matrix": _lib.XC_M_BALANCED_ACC,
+    "binary_gmean_on_conf_matrix": _lib.XC_M_GMEAN,
+    "binary_hmean_on_conf_matrix": _lib.XC_M_HMEAN,
+}
+
+
+class DeviceMetric:
+    """A callable binary metric that also carries its device descriptor.
+
+    Used for the closures the reference builds inside its wrappers (instance
+    precision with a fixed k, block_coordinate.py:821-822; the mixed utilities,
+    :862-865 and siblings): calling it evaluates the formula on the host exactly
+    like those closures, ``spec`` is what the kernels run.
+    """
+
+    def __init__(self, spec: MetricSpec, host_base: Callable, name: str):
+        self.spec = spec
+        self._host_base = host_base
+        self.__name__ = name
+
+    def __call__(self, tp, fp, fn, tn, **kwargs):
+        s = self.spec
+        if s.base == _lib.XC_M_PRECISION_AT_K:
+            base = tp / s.kf
+        elif s.base == _lib.XC_M_FBETA:
+            base = binary_fbeta_score_on_conf_matrix(tp, fp, fn, tn, beta=s.beta,
+                                                     epsilon=kwargs.get("epsilon", s.epsilon))
+        elif s.base == _lib.XC_M_ACCURACY:
+            base = self._host_base(tp, fp, fn, tn)
+        else:
+            base = self._host_base(tp, fp, fn, tn, epsilon=kwargs.get("epsilon", s.epsilon))
+        if s.mixed:
+            return (1 - s.alpha) * (tp / s.kf) + s.alpha * base / s.mf
+        return base
+
+
+def resolve_metric(binary_metric_func, metric_kwargs: Optional[Dict[str, Any]] = None) -> MetricSpec:
+    """Map `binary_metric_func` (+ `metric_kwargs`) to the descriptor the kernels
+    evaluate.  Raises ``NotImplementedError`` for callables that are not one of
+    the known formulas (no silent substitution, no host fallback)."""
+    kwargs = dict(metric_kwargs or {})
+    func = binary_metric_func
+    if isinstance(func, (list, tuple)):
+        if len(func) == 0:
+            raise ValueError("binary_metric_func list is empty")
+        specs = [resolve_metric(f, metric_kwargs) for f in func]
+        if any(s != specs[0] for s in specs[1:]):
+            raise NotImplementedError(
+                "a different binary metric per label is not supported by the MI355X kernels; "
+                "pass one metric for all labels")
+        return specs[0]
+    if isinstance(func, functools.partial):
+        if func.args:
+            raise NotImplementedError("positional functools.partial arguments are not supported")
+        kwargs = {**func.keywords, **kwargs}
+        func = func.func
+    if isinstance(func, DeviceMetric):
+        spec = func.spec
+    elif isinstance(func, MetricSpec):
+        spec = func
+    else:
+        base = getattr(func, "_xc_base", None)
+        if base is None and callable(func):
+            name = getattr(func, "__name__", "")
+            module = getattr(func, "__module__", "") or ""
+            if name in _BASE_BY_NAME and module.split(".")[-1] == "metrics":
+                base = _BASE_BY_NAME[name]
+        if base is None:
+            raise NotImplementedError(
+                f"binary_metric_func={getattr(func, '__name__', func)!r} is not one of the metrics the "
+                "MI355X kernels evaluate (binary_{precision,recall,fbeta_score,f1_score,jaccard_score,"
+                "balanced_accuracy,gmean,hmean,accuracy,precision_at_k}_on_conf_matrix or a DeviceMetric); "
+                "arbitrary Python callables cannot run on the GPU and there is no CPU fallback")
+        spec = MetricSpec(base=base)
+    allowed = {"epsilon", "beta", "k"}
+    unknown = set(kwargs) - allowed
+    if unknown:
+        raise NotImplementedError(f"metric_kwargs {sorted(unknown)} are not supported on device")
+    if "epsilon" in kwargs:
+        spec = replace(spec, epsilon=float(kwargs["epsilon"]))
+    if "beta" in kwargs:
+        if spec.base != _lib.XC_M_FBETA:
+            raise ValueError("metric_kwargs['beta'] only applies to the F-beta score")
+        spec = replace(spec, beta=float(kwargs["beta"]))
+    if "k" in kwargs:
+        spec = replace(spec, kf=float(kwargs["k"]))
+    return spec
+
+
+def host_values(spec: MetricSpec, tp, fp, fn, tn):
+    """Evaluate `spec` on host arrays (small vectors; used for reporting only)."""
+    table = {
+        _lib.XC_M_PRECISION_AT_K: lambda: tp / spec.kf,
+        _lib.XC_M_PRECISION: lambda: binary_precision_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
+        _lib.XC_M_RECALL: lambda: binary_recall_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
+        _lib.XC_M_FBETA: lambda: binary_fbeta_score_on_conf_matrix(tp, fp, fn, tn, spec.beta, spec.epsilon),
+        _lib.XC_M_JACCARD: lambda: binary_jaccard_score_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
+        _lib.XC_M_BALANCED_ACC: lambda: binary_balanced_accuracy_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
+        _lib.XC_M_GMEAN: lambda: binary_gmean_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
+        _lib.XC_M_HMEAN: lambda: binary_hmean_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
+        _lib.XC_M_ACCURACY: lambda: binary_accuracy_on_conf_matrix(tp, fp, fn, tn),
+    }
+    base = table[spec.base]()
+    if spec.mixed:
+        return (1 - spec.alpha) * (tp / spec.kf) + spec.alpha * base / spec.mf
+    return base

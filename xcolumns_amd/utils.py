@@ -1,0 +1,150 @@
+"""Host-side helpers of the path (mirrors the parts of
+/root/reference/xcolumns/utils.py the BCA / top-k path uses)."""
+from __future__ import annotations
+
+import inspect
+import logging
+import random
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+from scipy.sparse import csr_matrix
+
+logging.basicConfig()
+logger = logging.getLogger("xcolumns")  # same logger name as the reference (utils.py:21-23)
+logger.setLevel(logging.INFO)
+
+
+def log(msg: str, verbose: bool = True, level: int = logging.INFO):
+    if verbose:
+        logger.log(level, msg)
+
+
+def log_info(msg: str, verbose: bool = True):
+    log(msg, verbose, level=logging.INFO)
+
+
+def log_debug(msg: str, verbose: bool = True):
+    log(msg, verbose, level=logging.DEBUG)
+
+
+def log_warning(msg: str, verbose: bool = True):
+    log(msg, verbose, level=logging.WARNING)
+
+
+def log_error(msg: str, verbose: bool = True):
+    log(msg, verbose, level=logging.ERROR)
+
+
+def zeros_like(a, shape: Tuple[int, ...] = None, dtype=None):
+    """utils.py:52-69."""
+    if isinstance(a, np.ndarray):
+        return np.zeros_like(a, shape=shape, dtype=dtype)
+    if isinstance(a, csr_matrix):
+        return np.zeros(shape if shape is not None else a.shape, dtype=dtype if dtype is not None else a.dtype)
+    if isinstance(a, torch.Tensor):
+        return torch.zeros(shape if shape is not None else a.shape,
+                           dtype=dtype if dtype is not None else a.dtype, device=a.device)
+    raise ValueError(f"Unsupported type {type(a)}")
+
+
+def ones_like(a, shape: Tuple[int, ...] = None, dtype=None):
+    """utils.py:72-89."""
+    if isinstance(a, np.ndarray):
+        return np.ones_like(a, shape=shape, dtype=dtype)
+    if isinstance(a, csr_matrix):
+        return np.ones(shape if shape is not None else a.shape, dtype=dtype if dtype is not None else a.dtype)
+    if isinstance(a, torch.Tensor):
+        return torch.ones(shape if shape is not None else a.shape,
+                          dtype=dtype if dtype is not None else a.dtype, device=a.device)
+    raise ValueError(f"Unsupported type {type(a)}")
+
+
+def random_at_k_np(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[int] = None) -> np.ndarray:
+    """k random labels per row, the numpy Generator stream of utils.py:103-116
+    (``rng.choice(m, k, replace=False, shuffle=False)`` row by row)."""
+    n, m = shape
+    y_pred = np.zeros(shape, dtype=dtype)
+    rng = np.random.default_rng(seed)
+    labels_range = np.arange(m)
+    for i in range(n):
+        y_pred[i, rng.choice(labels_range, k, replace=False, shuffle=False)] = 1.0
+    return y_pred
+
+
+def random_at_k_csr(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[int] = None) -> csr_matrix:
+    """k random labels per row as CSR (utils.py:119-136).  The reference draws them
+    inside numba (numba_csr_functions.py:92-112: a partial Fisher-Yates shuffle on
+    ``random.randint``); numba keeps a private Mersenne-Twister whose stream is
+    not reproducible outside it, so this uses the same algorithm on CPython's
+    ``random`` -- same distribution, same stream as the un-JIT'd reference."""
+    n, m = shape
+    if seed is not None:
+        random.seed(seed)
+    indices = np.empty(n * k, dtype=np.int32)
+    base = np.arange(m, dtype=np.int32)
+    for i in range(n):
+        index = base.copy()
+        for t in range(k):
+            j = random.randint(t, m - 1)
+            index[t], index[j] = index[j], index[t]
+        indices[i * k:(i + 1) * k] = index[:k]
+    indptr = (np.arange(n + 1, dtype=np.int64) * k).astype(np.int32)
+    return construct_csr_matrix(np.ones(n * k, dtype=np.float32).astype(dtype), indices, indptr,
+                                dtype=dtype, shape=shape, sort_indices=True)
+
+
+def unpack_csr_matrix(matrix: csr_matrix):
+    return matrix.data, matrix.indices, matrix.indptr
+
+
+def unpack_csr_matrices(*matrices) -> List[np.ndarray]:
+    out = []
+    for mat in matrices:
+        out.extend(unpack_csr_matrix(mat))
+    return out
+
+
+def construct_csr_matrix(data, indices, indptr, dtype=None, shape=None, sort_indices=False) -> csr_matrix:
+    mat = csr_matrix((data, indices, indptr), dtype=dtype, shape=shape)
+    if sort_indices:
+        mat.sort_indices()
+    return mat
+
+
+def uniform_search(low: float, high: float, step: float, func: Callable) -> Tuple[float, float]:
+    """utils.py:174-184."""
+    best, best_val = low, func(low)
+    for i in np.arange(low + step, high, step):
+        score = func(i)
+        if score > best_val:
+            best, best_val = i, score
+    return best, best_val
+
+
+def ternary_search(low: float, high: float, eps: float, func: Callable) -> Tuple[float, float]:
+    """utils.py:187-201."""
+    while high - low > eps:
+        mid1 = low + (high - low) / 3
+        mid2 = high - (high - low) / 3
+        if func(mid1) < func(mid2):
+            high = mid2
+        else:
+            low = mid1
+    best = (low + high) / 2
+    return best, func(best)
+
+
+def add_kwargs_to_signature(func: Callable, func_with_kwargs: Callable, skip: Optional[List] = None) -> Callable:
+    """Expose the keyword arguments of `func_with_kwargs` in `func.__signature__`
+    (utils.py:209-230); the experiments filter kwargs through it."""
+    skip = skip or []
+    sig_with_kwargs = inspect.signature(func_with_kwargs)
+    sig_new = inspect.signature(func)
+    func.__signature__ = sig_new.replace(
+        parameters=[p for p in sig_new.parameters.values() if p.kind != inspect.Parameter.VAR_KEYWORD]
+        + [p for p in sig_with_kwargs.parameters.values()
+           if p.default != inspect.Parameter.empty and p.name not in skip]
+    )
+    return func
