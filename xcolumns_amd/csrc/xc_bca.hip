@@ -42,6 +42,7 @@ struct SweepParams {
     double *state;
     xc_metric metric;
     double nn;        // divisor n of the step (block_coordinate.py:229-231)
+    double inv_nn;    // 1 / nn, used by the non-exact arithmetic
     double n_counted; // rows counted in the statistics when not greedy
     int maximize;
     int greedy;
@@ -50,52 +51,115 @@ struct SweepParams {
     unsigned long long *changed;
 };
 
+// Order-preserving map from float64 to uint64 (larger gain -> larger key).  NaN
+// was mapped to -inf before.  Every finite/infinite double maps to a key >= 1
+// (-inf -> 0x000fffffffffffff), so key 0 marks "no candidate".
+__device__ __forceinline__ unsigned long long sortable_key(double g) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(g);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// x / nn: the reference divides (block_coordinate.py:252-264).  EXACT keeps the
+// IEEE division (bit-identical gains, used by the sequential mode that must
+// reproduce the reference's trajectory); otherwise one multiply by 1/nn -- the
+// gains move by <= 1 ulp, far inside the 1e-5 utility tolerance of the
+// concurrent mode, and the per-row critical path loses six divisions.
+template <bool EXACT>
+__device__ __forceinline__ double div_n(double x, double nn, double inv_nn) {
+    return EXACT ? x / nn : x * inv_nn;
+}
+
+// The row a wavefront works on: everything that does not depend on the
+// statistics, so it can be fetched ahead of time.
 template <typename T, int CH>
+struct RowData {
+    int idx[CH];
+    T eta[CH];
+    int old_id; // lane q < k: q-th column of the row's current prediction
+};
+
+// All lanes load (clamped to the row's last entry / the prediction's last slot):
+// straight-line code keeps the loads in flight under precise vmcnt waits instead
+// of exec-masked blocks; lanes past the row end are masked out by `p < r` later.
+template <typename T, int CH>
+__device__ __forceinline__ void load_row(const SweepParams<T> &P, int row, int s, int r, int lane,
+                                         RowData<T, CH> &d) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int p = lane + XC_WAVE * c;
+        const int pc = p < r ? p : r - 1;
+        d.idx[c] = P.indices[s + pc];
+        d.eta[c] = P.data[s + pc];
+    }
+    const int q = lane < P.k ? lane : P.k - 1;
+    d.old_id = P.pred_indices[(int64_t)row * P.k + q];
+}
+
+template <typename T, int CH, bool EXACT, bool HAS_ORDER>
 __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
     if (wave >= P.n_waves) return;
     const int k = P.k;
-    const double nn = P.nn;
+    const double nn = P.nn, inv_nn = P.inv_nn;
     const bool greedy = P.greedy != 0;
     const bool skip_tn = P.skip_tn != 0;
+    const int64_t W = P.n_waves;
+    const int64_t last = P.n_order - 1;
     unsigned long long n_changed = 0;
 
-    for (int64_t pos = wave; pos < P.n_order; pos += P.n_waves) {
-        const int64_t row = P.order ? (int64_t)P.order[pos] : pos;
-        const int s = P.indptr[row];
-        const int r = P.indptr[row + 1] - s;
+    // Software pipeline over the wave's positions pos, pos+W, pos+2W, ...:
+    // while row t is being scored, the CSR entries of row t+1, the indptr pair
+    // of row t+2 and the order entry of row t+3 are in flight.  None of these
+    // depends on the statistics, so fetching them early adds no staleness; the
+    // statistics themselves are gathered at the last moment.
+    auto row_at = [&](int64_t pos) -> int {
+        const int64_t q = pos < last ? pos : last; // clamp: tail prefetches stay in bounds
+        return HAS_ORDER ? P.order[q] : (int)q; // compile-time: no branch around the load
+    };
+    int64_t pos = wave;
+    int row0 = row_at(pos), row1 = row_at(pos + W), row2 = row_at(pos + 2 * W);
+    int s0 = P.indptr[row0], e0 = P.indptr[row0 + 1];
+    int s1 = P.indptr[row1], e1 = P.indptr[row1 + 1];
+    RowData<T, CH> cur;
+    load_row<T, CH>(P, row0, s0, e0 - s0, lane, cur);
+
+    for (; pos < P.n_order; pos += W) {
+        const int64_t row = row0;
+        const int r = e0 - s0;
         int32_t *p_idx = P.pred_indices + row * k;
         T *p_eta = P.pred_eta + row * k;
 
-        // current prediction of the row: lane q < k holds its q-th column id
-        const int old_id = (lane < k) ? p_idx[lane] : -1;
-
-        // candidates = the row's stored entries (the gains are only evaluated
-        // there: t_indices, block_coordinate.py:240, :248-250)
-        int idx[CH];
-        T eta[CH];
-        bool in_old[CH];
+        // ---- gather the statistics of the candidate labels (sc1 loads) ----
+        double tp[CH], fp[CH], sc[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int p = lane + XC_WAVE * c;
-            const bool valid = p < r;
-            idx[c] = valid ? P.indices[s + p] : -1;
-            eta[c] = valid ? P.data[s + p] : (T)0;
-            in_old[c] = false;
+            const double *st = P.state + (int64_t)cur.idx[c] * XC_STATE_STRIDE;
+            tp[c] = load_coherent(st + 0);
+            fp[c] = load_coherent(st + 1);
+            sc[c] = greedy ? load_coherent(st + 2) : st[2];
         }
 
-        // membership of each candidate in the current prediction, and the
-        // predicted columns the row does not store ("orphans": eta = 0, they
-        // contributed fp += 1, numba_csr_functions.py:200-203) -- only foreign
-        // initial predictions have them; they leave the prediction for good here
+        // ---- prefetch for the following rows (issued AFTER the gathers so the
+        // wait on the gathers does not also wait for these) ----
+        RowData<T, CH> nxt;
+        load_row<T, CH>(P, row1, s1, e1 - s1, lane, nxt);
+        const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
+        const int row3 = row_at(pos + 3 * W);
+
+        // ---- membership of the candidates in the current prediction; predicted
+        // columns the row does not store ("orphans": eta = 0, they contributed
+        // fp += 1, numba_csr_functions.py:200-203) leave the prediction here ----
+        bool in_old[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) in_old[c] = false;
         if (!greedy) {
             for (int q = 0; q < k; ++q) {
-                const int oid = __builtin_amdgcn_readlane(old_id, q);
+                const int oid = __builtin_amdgcn_readlane(cur.old_id, q);
                 bool hit_any = false;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    const bool hit = (idx[c] == oid);
+                    const bool hit = (cur.idx[c] == oid) && (lane + XC_WAVE * c < r);
                     in_old[c] = in_old[c] || hit;
                     hit_any = hit_any || hit;
                 }
@@ -104,112 +168,135 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             }
         }
 
-        // gather the statistics of the candidate labels and form the gains
-        double gain[CH];
+        // ---- gains (block_coordinate.py:248-282) ----
+        unsigned long long key[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int p = lane + XC_WAVE * c;
-            gain[c] = -INFINITY;
-            if (p < r) {
-                const double *st = P.state + (int64_t)idx[c] * XC_STATE_STRIDE;
-                double tp = load_coherent(st + 0);
-                double fp = load_coherent(st + 1);
-                double sc = greedy ? load_coherent(st + 2) : st[2];
-                const T e = eta[c];
+            key[c] = 0ull;
+            if (lane + XC_WAVE * c < r) {
+                const T e = cur.eta[c];
                 const T om = (T)1 - e; // (1 - t_data) in the input dtype, :253
                 const double ed = (double)e;
                 const double omd = (double)om;
+                double tpc = tp[c], fpc = fp[c], scc = sc[c];
                 // statistics without this row (:243-246, done in registers)
                 if (in_old[c]) {
-                    tp -= ed;
-                    fp -= omd;
+                    tpc -= ed;
+                    fpc -= omd;
                 }
-                if (!greedy) sc -= ed;
-                const double fn = sc - tp;
-                // rows counted besides this one
-                const double n1 = greedy ? (double)pos : (P.n_counted - 1.0);
-                const double tn = n1 - fp - sc;
+                if (!greedy) scc -= ed;
+                const double fn = scc - tpc;
+                const double n1 = greedy ? (double)pos : (P.n_counted - 1.0); // rows counted besides this one
+                const double tn = n1 - fpc - scc;
                 // :252-264
-                const double pos_tp = (tp + ed) / nn;
-                const double pos_fp = (fp + omd) / nn;
-                const double neg_fn = (fn + ed) / nn;
-                const double neg_tp = tp / nn;
-                const double neg_fp = fp / nn;
-                const double pos_fn = fn / nn;
-                // skip_tn: Etn is the constant -1, undivided (:260-261); all zeros in
-                // the greedy first sweep (:427)
+                const double pos_tp = div_n<EXACT>(tpc + ed, nn, inv_nn);
+                const double pos_fp = div_n<EXACT>(fpc + omd, nn, inv_nn);
+                const double neg_fn = div_n<EXACT>(fn + ed, nn, inv_nn);
+                const double neg_tp = div_n<EXACT>(tpc, nn, inv_nn);
+                const double neg_fp = div_n<EXACT>(fpc, nn, inv_nn);
+                const double pos_fn = div_n<EXACT>(fn, nn, inv_nn);
+                // skip_tn: Etn is the constant -1, undivided (:260-261); zeros in the
+                // greedy first sweep (:427)
                 double pos_tn = greedy ? 0.0 : -1.0, neg_tn = pos_tn;
                 if (!skip_tn) {
-                    neg_tn = (tn + omd) / nn;
-                    pos_tn = tn / nn;
+                    neg_tn = div_n<EXACT>(tn + omd, nn, inv_nn);
+                    pos_tn = div_n<EXACT>(tn, nn, inv_nn);
                 }
                 // :267-282
                 double g = metric_eval(P.metric, pos_tp, pos_fp, pos_fn, pos_tn) -
                            metric_eval(P.metric, neg_tp, neg_fp, neg_fn, neg_tn);
                 if (!P.maximize) g = -g;
-                gain[c] = nan_to_neg_inf(g);
+                key[c] = sortable_key(nan_to_neg_inf(g));
             }
         }
 
-        // numba_set_gains_csr -> numba_argtopk_csr (numba_csr_functions.py:455-466,
-        // :514-524): k rounds of wavefront arg-max (rows hold >= k entries)
-        bool in_new[CH];
+        // ---- top-k (numba_set_gains_csr -> numba_argtopk_csr,
+        // numba_csr_functions.py:455-466, :514-524).  The k-th largest key is found
+        // by bisection on the key bits with wave ballots: `thr` grows bit by bit
+        // while at least k candidates stay >= thr; it stops early as soon as
+        // exactly k do.  Equal keys at the boundary go to the lower position.
+        unsigned long long thr = 0ull;
+        const int kk = r < k ? r : k;
+        int n_ge = 0;
+        for (int bit = 63; bit >= 0; --bit) {
+            const unsigned long long cand = thr | (1ull << bit);
+            int cnt = 0;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) in_new[c] = false;
-        const int rounds = r < k ? r : k;
-        for (int round = 0; round < rounds; ++round) {
-            Best<double> b{-INFINITY, INT_MAX};
+            for (int c = 0; c < CH; ++c) cnt += __popcll(__ballot(key[c] >= cand));
+            if (cnt >= kk) {
+                thr = cand;
+                n_ge = cnt;
+                if (cnt == kk) break;
+            }
+        }
+        bool in_new[CH];
+        if (n_ge == kk) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) in_new[c] = key[c] >= thr && key[c] != 0ull;
+        } else {
+            // thr is the k-th largest key and it repeats: all larger keys, then
+            // the first (kk - #larger) of the equal ones in position order
+            int n_gt = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) n_gt += __popcll(__ballot(key[c] > thr));
+            int need = kk - n_gt;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const int p = lane + XC_WAVE * c;
-                if (p < r && !in_new[c] && beats(gain[c], p, b.g, b.p)) {
-                    b.g = gain[c];
-                    b.p = p;
-                }
+                const bool eq = key[c] == thr && key[c] != 0ull;
+                const unsigned long long m_eq = __ballot(eq);
+                const int before = __popcll(m_eq & lanemask_lt());
+                in_new[c] = (key[c] > thr) || (eq && before < need);
+                need -= __popcll(m_eq);
+                if (need < 0) need = 0;
             }
-            b = wave_argmax(b);
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (lane + XC_WAVE * c == b.p) in_new[c] = true;
         }
 
-        // write the new prediction (ascending columns) and push the change of
-        // the statistics (:290-293 minus :243-246) to memory
-        int base = 0;
+        // ---- write the new prediction (ascending columns) and push the change
+        // of the statistics (:290-293 minus :243-246) to memory ----
         bool any_change = false;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int p = lane + XC_WAVE * c;
-            const unsigned long long mask = __ballot(in_new[c]);
-            if (in_new[c]) {
-                const int slot = base + __popcll(mask & lanemask_lt());
-                p_idx[slot] = idx[c];
-                p_eta[slot] = eta[c];
-            }
-            base += __popcll(mask);
-            if (p < r) {
-                double *st = P.state + (int64_t)idx[c] * XC_STATE_STRIDE;
-                const double ed = (double)eta[c];
-                const double omd = (double)((T)1 - eta[c]);
-                if (greedy) {
-                    atomic_add_f64(st + 2, ed);
-                    if (in_new[c]) {
-                        atomic_add_f64(st + 0, ed);
-                        atomic_add_f64(st + 1, omd);
+        for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
+        const bool row_changed = __ballot(any_change) != 0ull;
+        if (row_changed || greedy) {
+            int base = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const unsigned long long mask = __ballot(in_new[c]);
+                if (in_new[c]) {
+                    const int slot = base + __popcll(mask & lanemask_lt());
+                    p_idx[slot] = cur.idx[c];
+                    p_eta[slot] = cur.eta[c];
+                }
+                base += __popcll(mask);
+                if (lane + XC_WAVE * c < r) {
+                    double *st = P.state + (int64_t)cur.idx[c] * XC_STATE_STRIDE;
+                    const double ed = (double)cur.eta[c];
+                    const double omd = (double)((T)1 - cur.eta[c]);
+                    if (greedy) {
+                        atomic_add_f64(st + 2, ed);
+                        if (in_new[c]) {
+                            atomic_add_f64(st + 0, ed);
+                            atomic_add_f64(st + 1, omd);
+                        }
+                    } else if (in_new[c] != in_old[c]) {
+                        const double sgn = in_new[c] ? 1.0 : -1.0;
+                        atomic_add_f64(st + 0, sgn * ed);
+                        atomic_add_f64(st + 1, sgn * omd);
                     }
-                } else if (in_new[c] != in_old[c]) {
-                    any_change = true;
-                    const double sgn = in_new[c] ? 1.0 : -1.0;
-                    atomic_add_f64(st + 0, sgn * ed);
-                    atomic_add_f64(st + 1, sgn * omd);
                 }
             }
+            if (row_changed) ++n_changed;
         }
-        if (__ballot(any_change) != 0ull) ++n_changed;
 
-        // exact mode: this wave's atomics must have been performed before it
+        // sequential mode: this wave's atomics must have been performed before it
         // gathers statistics for its next row
         if (P.n_waves == 1) __builtin_amdgcn_s_waitcnt(0);
+
+        // ---- rotate the pipeline ----
+        cur = nxt;
+        row0 = row1; s0 = s1; e0 = e1;
+        row1 = row2; s1 = s2; e1 = e2;
+        row2 = row3;
     }
     if (P.changed && lane == 0 && n_changed)
         atomicAdd(P.changed, n_changed);
@@ -327,15 +414,29 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
     tn[j] = skip_tn ? -1.0 : (n_counted - st[1] - st[2]);
 }
 
-template <typename T>
-static void launch_sweep(const SweepParams<T> &P, int ch, hipStream_t st) {
+template <typename T, bool EXACT, bool HAS_ORDER>
+static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
     const int blocks = (P.n_waves + 3) / 4;
     switch (ch) {
-    case 1: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 1>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 2: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 2>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 4: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 4>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 8: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 8>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    default: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 16>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 1: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 1, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 2, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 4, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 8, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    default: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 16, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    }
+}
+
+// n_waves == 1 is the sequential mode that must reproduce the reference's
+// trajectory: it keeps the reference's divisions
+template <typename T>
+static void launch_sweep(const SweepParams<T> &P, int ch, hipStream_t st) {
+    const bool exact = P.n_waves == 1;
+    if (P.order) {
+        if (exact) launch_sweep_impl<T, true, true>(P, ch, st);
+        else launch_sweep_impl<T, false, true>(P, ch, st);
+    } else {
+        if (exact) launch_sweep_impl<T, true, false>(P, ch, st);
+        else launch_sweep_impl<T, false, false>(P, ch, st);
     }
 }
 
@@ -462,13 +563,13 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
                                  static_cast<float *>(pred_eta), k, state, *metric_host, (double)n_norm,
-                                 (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                 1.0 / (double)n_norm, (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                  reinterpret_cast<unsigned long long *>(changed)};
         xc::launch_sweep<float>(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
                                   static_cast<double *>(pred_eta), k, state, *metric_host, (double)n_norm,
-                                  (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                  1.0 / (double)n_norm, (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                   reinterpret_cast<unsigned long long *>(changed)};
         xc::launch_sweep<double>(P, ch, st);
     }

@@ -28,22 +28,81 @@ __device__ __forceinline__ int lower_bound_col(const int32_t *indices, int lo, i
 // by binary search -- the rows are a few hundred bytes and stay in L1/L2.
 //
 // The reference's merges + `result[idx] += data` scatter give these rules when
-// a column id repeats in a y_pred row (the padding top-k leaves in short rows):
+// a column id repeats in a sorted y_pred row:
 //   tp: only the first of the repeats can match y_true (:128-139);
 //   fp: every repeat emits a value but the scatter keeps the last one, and only
 //       the first repeat is "matched" (:199-212, :254);
 //   fn: a y_true entry pairs with the first repeat (:199-212).
+// Rows that are NOT sorted (the reference's own top-k leaves "[3, 0, 0]" in a row
+// with fewer than k entries: stored ids, then column-0 padding,
+// numba_csr_functions.py:599-601) go through `merge_row_sequential`, which replays
+// the three two-pointer merges literally in one lane; it covers rows of up to
+// XC_SEQ_CAP entries each -- longer unsorted rows are outside the contract
+// (:121 "requires sorted indices").
+#define XC_SEQ_CAP 64
+
+template <typename T>
+__device__ void scatter_last_wins(double *dst, const int *eidx, const double *eval, int c) {
+    for (int e = 0; e < c; ++e) {
+        bool later = false;
+        for (int f = e + 1; f < c; ++f) later = later || (eidx[f] == eidx[e]);
+        if (!later) atomic_add_f64(dst + eidx[e], eval[e]);
+    }
+}
+
+template <typename T>
+__device__ void merge_row_sequential(const int32_t *ti, const T *td, int tc, const int32_t *pi, const T *pd,
+                                     int pc, double *tp, double *fp, double *fn, int *eidx, double *eval) {
+    // tp: numba_csr_vec_mul_vec(pred, true)  (:124-140)
+    int i = 0, j = 0, c = 0;
+    while (i < pc && j < tc) {
+        if (pi[i] < ti[j]) ++i;
+        else if (pi[i] == ti[j]) { eidx[c] = pi[i]; eval[c] = (double)(T)(pd[i] * td[j]); ++c; ++i; ++j; }
+        else ++j;
+    }
+    scatter_last_wins<T>(tp, eidx, eval, c);
+    // fp: numba_csr_vec_mul_ones_minus_vec(pred, true)  (:195-213)
+    i = j = c = 0;
+    while (i < pc) {
+        if (j >= tc || pi[i] < ti[j]) { eidx[c] = pi[i]; eval[c] = (double)pd[i]; ++c; ++i; }
+        else if (pi[i] == ti[j]) { eidx[c] = pi[i]; eval[c] = (double)(T)((double)pd[i] * (1.0 - (double)td[j])); ++c; ++i; ++j; }
+        else ++j;
+    }
+    scatter_last_wins<T>(fp, eidx, eval, c);
+    // fn: numba_csr_vec_mul_ones_minus_vec(true, pred)
+    i = j = c = 0;
+    while (i < tc) {
+        if (j >= pc || ti[i] < pi[j]) { eidx[c] = ti[i]; eval[c] = (double)td[i]; ++c; ++i; }
+        else if (ti[i] == pi[j]) { eidx[c] = ti[i]; eval[c] = (double)(T)((double)td[i] * (1.0 - (double)pd[j])); ++c; ++i; ++j; }
+        else ++j;
+    }
+    scatter_last_wins<T>(fn, eidx, eval, c);
+}
+
 template <typename T>
 __global__ __launch_bounds__(XC_BLOCK) void confusion_csr_kernel(
     int64_t n, const int32_t *t_indptr, const int32_t *t_indices, const T *t_data,
     const int32_t *p_indptr, const int32_t *p_indices, const T *p_data, double *tp, double *fp,
     double *fn, int n_waves) {
+    __shared__ int s_eidx[XC_BLOCK / XC_WAVE][XC_SEQ_CAP];
+    __shared__ double s_eval[XC_BLOCK / XC_WAVE][XC_SEQ_CAP];
     const int lane = lane_id();
-    const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    const int wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + wib;
     if (wave >= n_waves) return;
     for (int64_t row = wave; row < n; row += n_waves) {
         const int ts = t_indptr[row], te = t_indptr[row + 1];
         const int ps = p_indptr[row], pe = p_indptr[row + 1];
+        // sortedness (non-decreasing) of both rows
+        bool bad = false;
+        for (int q = ps + 1 + lane; q < pe; q += XC_WAVE) bad = bad || (p_indices[q] < p_indices[q - 1]);
+        for (int t = ts + 1 + lane; t < te; t += XC_WAVE) bad = bad || (t_indices[t] < t_indices[t - 1]);
+        if (__ballot(bad) != 0ull && (pe - ps) <= XC_SEQ_CAP && (te - ts) <= XC_SEQ_CAP) {
+            if (lane == 0)
+                merge_row_sequential<T>(t_indices + ts, t_data + ts, te - ts, p_indices + ps, p_data + ps, pe - ps,
+                                        tp, fp, fn, s_eidx[wib], s_eval[wib]);
+            continue;
+        }
         for (int q = ps + lane; q < pe; q += XC_WAVE) {
             const int col = p_indices[q];
             const T pv = p_data[q];
