@@ -85,7 +85,7 @@ def main():
 
     from xcolumns_amd import _device as D
     from xcolumns_amd import _lib
-    from xcolumns_amd.block_coordinate import BcaCsrEngine, default_bca_waves
+    from xcolumns_amd.block_coordinate import BcaCsrEngine, WavePolicy
     from xcolumns_amd.distributed import TorchComm
     from xcolumns_amd.metrics import MetricSpec
     from xcolumns_amd.synthetic import WORKLOADS, make_csr
@@ -120,14 +120,19 @@ def main():
         rng.shuffle(order)
         orders[s] = torch.from_numpy(order.astype(np.int32)).to(dev)
 
-    n_waves = args.waves if args.waves > 0 else default_bca_waves(n)
+    policy = WavePolicy(n, fixed=args.waves if args.waves > 0 else None)
     eng.init_top()
     eng.reset_state(greedy=False)
     u0 = eng.recompute_utility_sum(n_u) / m
 
     ev_pairs = []
+    waves_used = []
+    state = {"changed": None}
 
     def step(s, timed):
+        """One BCA iteration exactly as predict_using_bc_with_0approx runs it."""
+        n_waves = policy.next(state["changed"])
+        eng.changed.zero_()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -135,11 +140,15 @@ def main():
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
-        return eng.recompute_utility_sum(n_u) / m
+            waves_used.append(n_waves)
+        u = eng.recompute_utility_sum(n_u) / m
+        state["changed"] = eng.rows_changed()
+        return u
 
     utilities = []
     for s in range(args.warmup):
         step(s, False)
+    state["changed"] = None
     # the timed steps are sweeps 1..K of a fresh run: back to the top-k prediction
     # (untimed), so the measured mix of changed / unchanged rows is a real run's
     eng.init_top()
@@ -186,7 +195,7 @@ def main():
                             f"{'Zipf(1)' if args.zipf else 'uniform'} label popularity, BCA macro-F1 k={K}, "
                             f"init top-k, skip_tn, float32 scores, float64 statistics",
                 "rows_per_gpu": n, "labels": m, "nnz_per_row": R_NNZ, "k": K,
-                "concurrent_wavefronts": n_waves,
+                "concurrent_wavefronts_per_sweep": waves_used,
                 "step": "sweep kernel + tp/fp recompute + (all-reduce) + utility + D2H",
             },
             "roofline": {

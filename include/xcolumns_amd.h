@@ -94,13 +94,15 @@ int xc_device_info(int *cu_count, int *waves_per_cu, char *arch, int arch_len);
  * reference's padding (column 0, value 1).  out_data[n*k] receives 1 (or the
  * gain when keep_scores).  out_eta (optional, n*k, `dtype`) receives the
  * y_proba value of each chosen entry (0 for padding) -- the BCA driver keeps it
- * next to the prediction.  a, b: optional, length m, already of `dtype`.
+ * next to the prediction.  out_sel (optional, one byte per stored entry of
+ * y_proba) receives 1 for the chosen entries and 0 for the others.
+ * a, b: optional, length m, already of `dtype`.
  * max_row_nnz: longest row (<= XC_MAX_ROW_NNZ); it selects how many candidates a
  * lane keeps in registers. */
 int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices,
                 const void *data, int dtype, int max_row_nnz, int k, const void *a,
                 const void *b, int keep_scores, int32_t *out_indices, void *out_data,
-                void *out_eta, void *stream);
+                void *out_eta, uint8_t *out_sel, void *stream);
 
 /* k == 0 branch (numba_csr_functions.py:631-653, :516-517): a row keeps the
  * entries whose gain >= th.  Two calls: count -> (caller does the exclusive
@@ -147,10 +149,13 @@ int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_p
 /* For a prediction given as column ids (pred_indices[n*k], k per row), look up
  * each id in its row of y_proba: pred_eta[n*k] <- the stored value, or 0 when the
  * row does not hold that column (the reference treats it as eta = 0,
- * numba_csr_functions.py:200-203). */
+ * numba_csr_functions.py:200-203).  sel (optional, one byte per stored entry,
+ * zeroed by the caller) gets 1 at the entries found; orphans (optional, n*k)
+ * gets the column id of every predicted column its row does NOT store, else -1. */
 int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indices,
                            const void *data, int dtype, const int32_t *pred_indices,
-                           int k, void *pred_eta, void *stream);
+                           int k, void *pred_eta, uint8_t *sel, int32_t *orphans,
+                           void *stream);
 
 /* state[j].s += column sums of y_proba over its nnz stored entries (one-off;
  * state zeroed by the caller). */
@@ -186,7 +191,14 @@ int xc_utility_finish_host(const double *partials, double *out_host, void *strea
  * (:212-293) as the body, for k > 0 and rows holding >= k entries.
  *   order        int32[n_order] row ids in visiting order, or NULL for 0..n_order-1
  *   n_norm       the divisor `n` of the step (:229-231)
- *   pred_*       the prediction, updated in place
+ *   pred_*       the prediction (k column ids + their y_proba values per row),
+ *                rewritten for the rows that change
+ *   sel          one byte per stored entry of y_proba: 1 = in the prediction; this
+ *                is what the sweep reads to know a row's current prediction
+ *   orphans      optional [n*k] from xc_bca_gather_pred_eta: predicted columns a
+ *                row does not store; they leave the prediction when the row is
+ *                visited (pass it for the first sweep after a foreign
+ *                initialisation, NULL afterwards)
  *   state        per-label records, updated with float64 atomics
  *   greedy       first sweep of init_y_pred="greedy": rows are added as they are
  *                visited (:243 skipped, stats start from zero)
@@ -198,7 +210,8 @@ int xc_utility_finish_host(const double *partials, double *out_host, void *strea
 int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      const int32_t *indptr, const int32_t *indices, const void *data,
                      int dtype, int max_row_nnz, int32_t *pred_indices,
-                     void *pred_eta, int k, double *state,
+                     void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
+                     double *state,
                      const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 

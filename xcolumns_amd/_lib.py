@@ -48,7 +48,7 @@ SIGNATURES = {
     "xc_last_error": (c_char_p, []),
     "xc_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
     "xc_topk_csr": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
-                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_threshold_count_csr": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_threshold_fill_csr": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double,
@@ -60,14 +60,14 @@ SIGNATURES = {
     "xc_confusion_dense": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "xc_bca_gather_pred_eta": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                       c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_colsum_csr": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_accumulate_pred": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_commit_utility": (c_int, [c_int64, c_int64, c_double, c_void_p, c_void_p,
                                       POINTER(XcMetric), c_int, c_void_p, c_void_p]),
     "xc_utility_finish_host": (c_int, [c_void_p, POINTER(c_double), c_void_p]),
     "xc_bca_sweep_csr": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_int, c_void_p, c_void_p, c_int, c_void_p, POINTER(XcMetric),
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, POINTER(XcMetric),
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xc_bca_state_unpack": (c_int, [c_int64, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),

@@ -51,21 +51,43 @@ from .types import DenseMatrix, Matrix, is_dense, is_matrix
 from .utils import add_kwargs_to_signature, log_info, log_warning, random_at_k_csr, random_at_k_np
 from .weighted_prediction import topk_csr_device, topk_dense_device
 
-# rows in flight against statistics that miss each other's update, as a
-# fraction of the rows: n_waves ~ n / STALE_DIV (DESIGN.md "staleness")
-_STALE_DIV = int(os.environ.get("XCOLUMNS_BCA_STALE_DIV", "64"))
-_MIN_WAVES = 64
+# ---------------------------------------------------------------------------
+# how many wavefronts walk the visiting order concurrently
+# ---------------------------------------------------------------------------
+# The reference's sweep is sequential; here W rows are in flight at once and miss
+# each other's update.  Measured on MI355X (DESIGN.md "staleness"): the per-sweep
+# utility differs from the sequential sweep's by about
+#     c * (rows that change in the sweep / n) * (W / n),   c ~ 0.7e-2 .. 2e-2,
+# and the difference heals in the following sweeps.  The default keeps that
+# product below XCOLUMNS_BCA_STALE_BUDGET for every sweep, using the previous
+# sweep's number of changed rows (n/2 before the first): W grows as the
+# optimisation converges, so late sweeps use the whole GPU.
+_STALE_BUDGET = float(os.environ.get("XCOLUMNS_BCA_STALE_BUDGET", "2e-3"))
+_MIN_WAVES = 16
+
+
+class WavePolicy:
+    """Number of concurrent wavefronts for the next sweep."""
+
+    def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None):
+        env = os.environ.get("XCOLUMNS_BCA_WAVES")
+        self.fixed = int(fixed) if fixed else (int(env) if env else None)
+        self.n = max(1, int(n_order))
+        self.budget = _STALE_BUDGET if budget is None else float(budget)
+        info = _lib.device_info()
+        self.cap = info["cu_count"] * info["waves_per_cu"]
+
+    def next(self, changed_prev: Optional[int] = None) -> int:
+        if self.fixed:
+            return max(1, min(self.fixed, self.n))
+        changed = self.n / 2 if changed_prev is None else max(1, int(changed_prev))
+        want = int(self.budget * self.n * self.n / changed)
+        return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
 
 
 def default_bca_waves(n_order: int) -> int:
-    """How many wavefronts walk the visiting order concurrently by default."""
-    env = os.environ.get("XCOLUMNS_BCA_WAVES")
-    if env:
-        return max(1, int(env))
-    info = _lib.device_info()
-    cap = info["cu_count"] * info["waves_per_cu"]
-    want = max(_MIN_WAVES, n_order // max(1, _STALE_DIV))
-    return int(max(1, min(cap, want, n_order)))
+    """Concurrent wavefronts of a first sweep under the default policy."""
+    return WavePolicy(n_order).next(None)
 
 
 # ---------------------------------------------------------------------------
@@ -104,19 +126,28 @@ class BcaCsrEngine:
         self.changed = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pred_idx: Optional[torch.Tensor] = None
         self.pred_eta: Optional[torch.Tensor] = None
+        # one byte per stored entry of y_proba: is it in the row's current prediction
+        self.sel = torch.zeros(max(1, csr.nnz), dtype=torch.uint8, device=dev)
+        self.orphans: Optional[torch.Tensor] = None
 
     # -- initial prediction --------------------------------------------------
     def init_top(self):
         """predict_top_k (block_coordinate.py:40)."""
-        self.pred_idx, _, self.pred_eta = topk_csr_device(self.csr, self.k, want_eta=True)
+        self.pred_idx, _, self.pred_eta = topk_csr_device(self.csr, self.k, want_eta=True, out_sel=self.sel)
+        self.orphans = None
 
     def init_indices(self, pred_idx: torch.Tensor):
-        """An explicit prediction: k column ids per row."""
+        """An explicit prediction: k column ids per row.  Columns a row does not store
+        ("orphans") are kept aside; they leave the prediction in the first sweep."""
         c = self.csr
         self.pred_idx = pred_idx.to(device=self.dev, dtype=torch.int32).contiguous()
         self.pred_eta = torch.empty(c.n * self.k, dtype=c.data.dtype, device=self.dev)
+        self.sel.zero_()
+        orphans = torch.empty(c.n * self.k, dtype=torch.int32, device=self.dev)
         _lib.call("xc_bca_gather_pred_eta", c.n, D.ptr(c.indptr), D.ptr(c.indices), D.ptr(c.data), c.code,
-                  D.ptr(self.pred_idx), self.k, D.ptr(self.pred_eta), D.stream())
+                  D.ptr(self.pred_idx), self.k, D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(orphans),
+                  D.stream())
+        self.orphans = orphans if bool((orphans >= 0).any().item()) else None
 
     # -- statistics -------------------------------------------------------------
     def reset_state(self, greedy: bool):
@@ -165,9 +196,18 @@ class BcaCsrEngine:
         c = self.csr
         _lib.call("xc_bca_sweep_csr", int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx),
-                  D.ptr(self.pred_eta), self.k, D.ptr(self.state), ctypes.byref(self.gain_metric),
-                  int(self.maximize), int(bool(greedy)), int(self.skip_tn), int(n_waves),
-                  D.ptr(self.changed), D.stream())
+                  D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(self.orphans), self.k, D.ptr(self.state),
+                  ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
+                  int(n_waves), D.ptr(self.changed), D.stream())
+        # every row was visited: no orphan is left in any prediction
+        if n_order >= c.n:
+            self.orphans = None
+
+    def rows_changed(self) -> int:
+        """Rows whose prediction changed since `changed` was zeroed (all ranks)."""
+        if self.comm is not None:
+            self.comm.all_reduce(self.changed)
+        return int(self.changed.item())
 
     def confusion_vectors(self):
         """(tp, fp, fn, tn) float64 tensors on the GPU, the reference's four vectors."""
@@ -253,7 +293,8 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
         eng.init_indices(torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)))
 
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
-    n_waves = int(bca_waves) if bca_waves else default_bca_waves(n_u)
+    policy = WavePolicy(n_u, fixed=bca_waves)
+    changed_prev = None
     new_utility = None
     for j in range(1, max_iters + 1):
         log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
@@ -273,10 +314,12 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
             old_utility = old_utility / m
 
         log_info("    Doing block coordinate optimization steps ...", verbose)
-        eng.sweep(order, n_u, n_waves, greedy=greedy)
+        eng.changed.zero_()
+        eng.sweep(order, n_u, policy.next(changed_prev), greedy=greedy)
         if greedy:
             eng.sync_column_sums()
         new_utility_sum = eng.recompute_utility_sum(n_u)
+        changed_prev = eng.rows_changed()
         new_utility = new_utility_sum / m if metric_aggregation == "mean" else new_utility_sum
 
         greedy = False

@@ -38,6 +38,8 @@ struct SweepParams {
     const T *data;
     int32_t *pred_indices;
     T *pred_eta;
+    uint8_t *sel;           // per stored entry of y_proba: 1 = currently predicted
+    const int32_t *orphans; // optional [n*k]: predicted columns the row does not store, -1 = none
     int k;
     double *state;
     xc_metric metric;
@@ -49,7 +51,22 @@ struct SweepParams {
     int skip_tn;
     int n_waves;
     unsigned long long *changed;
+    unsigned long long *stamps; // diagnostic builds only (-DXC_STAMPS): per-phase cycle sums
 };
+
+// In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with
+// -DXC_STAMPS, never in the shipped library.  One asm statement = s_memtime plus
+// its own lgkmcnt wait; the sums go to a buffer no other code reads.
+#ifdef XC_STAMPS
+#define XC_NSTAMP 8
+#define XC_STAMP_DECL unsigned long long st_prev = 0, st_sum[XC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define XC_STAMP_START() do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_prev = t_; } while (0)
+#define XC_STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_sum[i] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define XC_STAMP_DECL
+#define XC_STAMP_START()
+#define XC_STAMP(i)
+#endif
 
 // Order-preserving map from float64 to uint64 (larger gain -> larger key).  NaN
 // was mapped to -inf before.  Every finite/infinite double maps to a key >= 1
@@ -75,24 +92,67 @@ template <typename T, int CH>
 struct RowData {
     int idx[CH];
     T eta[CH];
-    int old_id; // lane q < k: q-th column of the row's current prediction
+    uint8_t sel[CH]; // is the entry in the row's current prediction
 };
 
-// All lanes load (clamped to the row's last entry / the prediction's last slot):
-// straight-line code keeps the loads in flight under precise vmcnt waits instead
-// of exec-masked blocks; lanes past the row end are masked out by `p < r` later.
+// All lanes load (clamped to the row's last entry): straight-line code keeps the
+// loads in flight under precise vmcnt waits instead of exec-masked blocks; lanes
+// past the row end are masked out by `p < r` later.
 template <typename T, int CH>
-__device__ __forceinline__ void load_row(const SweepParams<T> &P, int row, int s, int r, int lane,
-                                         RowData<T, CH> &d) {
+__device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, int lane, RowData<T, CH> &d) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int p = lane + XC_WAVE * c;
         const int pc = p < r ? p : r - 1;
         d.idx[c] = P.indices[s + pc];
         d.eta[c] = P.data[s + pc];
+        d.sel[c] = P.sel[s + pc];
     }
-    const int q = lane < P.k ? lane : P.k - 1;
-    d.old_id = P.pred_indices[(int64_t)row * P.k + q];
+}
+
+// ---- wavefront reductions on DPP (gfx9 row_shr / row_bcast) -------------------
+// v_max_u32_dpp etc.: one VALU instruction per step, no LDS crossbar.  After the
+// four row_shr steps lane 15 of each 16-lane row holds the row's result;
+// row_bcast:15 / row_bcast:31 carry it across rows so lane 63 holds the wave's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_src(unsigned identity, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ unsigned wave_umax32(unsigned v) {
+    v = max(v, dpp_src<0x111, 0xF>(0u, v)); // row_shr:1
+    v = max(v, dpp_src<0x112, 0xF>(0u, v)); // row_shr:2
+    v = max(v, dpp_src<0x114, 0xF>(0u, v)); // row_shr:4
+    v = max(v, dpp_src<0x118, 0xF>(0u, v)); // row_shr:8
+    v = max(v, dpp_src<0x142, 0xA>(0u, v)); // row_bcast:15 into rows 1, 3
+    v = max(v, dpp_src<0x143, 0xC>(0u, v)); // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ unsigned wave_umin32(unsigned v) {
+    v = min(v, dpp_src<0x111, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x112, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x114, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x118, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x142, 0xA>(~0u, v));
+    v = min(v, dpp_src<0x143, 0xC>(~0u, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// 64-bit max / min as two 32-bit reductions: high words first, then the low words
+// of the lanes that hold the winning high word
+__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned H = wave_umax32(hi);
+    const unsigned L = wave_umax32(hi == H ? lo : 0u);
+    return ((unsigned long long)H << 32) | L;
+}
+
+__device__ __forceinline__ unsigned long long wave_umin64(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned H = wave_umin32(hi);
+    const unsigned L = wave_umin32(hi == H ? lo : ~0u);
+    return ((unsigned long long)H << 32) | L;
 }
 
 template <typename T, int CH, bool EXACT, bool HAS_ORDER>
@@ -122,8 +182,10 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     int s0 = P.indptr[row0], e0 = P.indptr[row0 + 1];
     int s1 = P.indptr[row1], e1 = P.indptr[row1 + 1];
     RowData<T, CH> cur;
-    load_row<T, CH>(P, row0, s0, e0 - s0, lane, cur);
+    load_row<T, CH>(P, s0, e0 - s0, lane, cur);
 
+    XC_STAMP_DECL;
+    XC_STAMP_START();
     for (; pos < P.n_order; pos += W) {
         const int64_t row = row0;
         const int r = e0 - s0;
@@ -143,31 +205,27 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // ---- prefetch for the following rows (issued AFTER the gathers so the
         // wait on the gathers does not also wait for these) ----
         RowData<T, CH> nxt;
-        load_row<T, CH>(P, row1, s1, e1 - s1, lane, nxt);
+        load_row<T, CH>(P, s1, e1 - s1, lane, nxt);
         const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
         const int row3 = row_at(pos + 3 * W);
+        XC_STAMP(0); // issue gathers + prefetches
 
-        // ---- membership of the candidates in the current prediction; predicted
-        // columns the row does not store ("orphans": eta = 0, they contributed
-        // fp += 1, numba_csr_functions.py:200-203) leave the prediction here ----
+        // ---- membership of the candidates in the current prediction comes with
+        // the row (sel flags).  Predicted columns the row does not store ("orphans":
+        // eta = 0, they contributed fp += 1, numba_csr_functions.py:200-203) exist
+        // only in foreign initial predictions; they leave the prediction here ----
         bool in_old[CH];
+        int n_old = 0;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) in_old[c] = false;
-        if (!greedy) {
-            for (int q = 0; q < k; ++q) {
-                const int oid = __builtin_amdgcn_readlane(cur.old_id, q);
-                bool hit_any = false;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const bool hit = (cur.idx[c] == oid) && (lane + XC_WAVE * c < r);
-                    in_old[c] = in_old[c] || hit;
-                    hit_any = hit_any || hit;
-                }
-                if (__ballot(hit_any) == 0ull && lane == 0)
-                    atomic_add_f64(P.state + (int64_t)oid * XC_STATE_STRIDE + 1, -1.0);
-            }
+        for (int c = 0; c < CH; ++c) {
+            in_old[c] = !greedy && cur.sel[c] != 0 && (lane + XC_WAVE * c < r);
+            n_old += __popcll(__ballot(in_old[c]));
         }
-
+        if (P.orphans && !greedy && lane < k) {
+            const int oid = P.orphans[row * k + lane];
+            if (oid >= 0) atomic_add_f64(P.state + (int64_t)oid * XC_STATE_STRIDE + 1, -1.0);
+        }
+        XC_STAMP(1); // membership
         // ---- gains (block_coordinate.py:248-282) ----
         unsigned long long key[CH];
 #pragma unroll
@@ -211,48 +269,89 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         }
 
         // ---- top-k (numba_set_gains_csr -> numba_argtopk_csr,
-        // numba_csr_functions.py:455-466, :514-524).  The k-th largest key is found
-        // by bisection on the key bits with wave ballots: `thr` grows bit by bit
-        // while at least k candidates stay >= thr; it stops early as soon as
-        // exactly k do.  Equal keys at the boundary go to the lower position.
-        unsigned long long thr = 0ull;
+        // numba_csr_functions.py:455-466, :514-524).
+        // Fast path: start from the current prediction and swap its worst member
+        // for the best outsider while the outsider is strictly better -- the set
+        // is the top-k exactly when no such swap is left, and most rows need none.
+        // Two DPP wave reductions per check.  Any tie at the boundary, or a
+        // prediction that does not hold exactly k of the row's entries, goes to
+        // the exact path below.
         const int kk = r < k ? r : k;
-        int n_ge = 0;
-        for (int bit = 63; bit >= 0; --bit) {
-            const unsigned long long cand = thr | (1ull << bit);
-            int cnt = 0;
+        bool in_new[CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) cnt += __popcll(__ballot(key[c] >= cand));
-            if (cnt >= kk) {
-                thr = cand;
-                n_ge = cnt;
-                if (cnt == kk) break;
+        for (int c = 0; c < CH; ++c) in_new[c] = in_old[c];
+        bool exact_path = (n_old != kk);
+        if (!exact_path) {
+            for (int it = 0; it <= kk; ++it) {
+                unsigned long long lmin = ~0ull, lmax = 0ull;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (in_new[c]) lmin = key[c] < lmin ? key[c] : lmin;
+                    else lmax = key[c] > lmax ? key[c] : lmax; // key 0 = no candidate
+                }
+                const unsigned long long smin = wave_umin64(lmin);
+                const unsigned long long umax = wave_umax64(lmax);
+                if (umax < smin) break;
+                int n_min = 0, n_max = 0;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    n_min += __popcll(__ballot(in_new[c] && key[c] == smin));
+                    n_max += __popcll(__ballot(!in_new[c] && key[c] == umax));
+                }
+                if (umax == smin || n_min != 1 || n_max != 1 || it == kk) {
+                    exact_path = true;
+                    break;
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (in_new[c] && key[c] == smin) in_new[c] = false;
+                    else if (!in_new[c] && key[c] == umax) in_new[c] = true;
+                }
             }
         }
-        bool in_new[CH];
-        if (n_ge == kk) {
+        if (exact_path) {
+            // The k-th largest key by bisection on the key bits with wave ballots:
+            // `thr` grows bit by bit while at least k candidates stay >= thr and
+            // stops early once exactly k do.  Equal keys at the boundary go to the
+            // lower position (= lower column id).
+            unsigned long long thr = 0ull;
+            int n_ge = 0;
+            for (int bit = 63; bit >= 0; --bit) {
+                const unsigned long long cand = thr | (1ull << bit);
+                int cnt = 0;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) in_new[c] = key[c] >= thr && key[c] != 0ull;
-        } else {
-            // thr is the k-th largest key and it repeats: all larger keys, then
-            // the first (kk - #larger) of the equal ones in position order
-            int n_gt = 0;
+                for (int c = 0; c < CH; ++c) cnt += __popcll(__ballot(key[c] >= cand));
+                if (cnt >= kk) {
+                    thr = cand;
+                    n_ge = cnt;
+                    if (cnt == kk) break;
+                }
+            }
+            if (n_ge == kk) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c) n_gt += __popcll(__ballot(key[c] > thr));
-            int need = kk - n_gt;
+                for (int c = 0; c < CH; ++c) in_new[c] = key[c] >= thr && key[c] != 0ull;
+            } else {
+                // thr is the k-th largest key and it repeats: all larger keys, then
+                // the first (kk - #larger) of the equal ones in position order
+                int n_gt = 0;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const bool eq = key[c] == thr && key[c] != 0ull;
-                const unsigned long long m_eq = __ballot(eq);
-                const int before = __popcll(m_eq & lanemask_lt());
-                in_new[c] = (key[c] > thr) || (eq && before < need);
-                need -= __popcll(m_eq);
-                if (need < 0) need = 0;
+                for (int c = 0; c < CH; ++c) n_gt += __popcll(__ballot(key[c] > thr));
+                int need = kk - n_gt;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const bool eq = key[c] == thr && key[c] != 0ull;
+                    const unsigned long long m_eq = __ballot(eq);
+                    const int before = __popcll(m_eq & lanemask_lt());
+                    in_new[c] = (key[c] > thr) || (eq && before < need);
+                    need -= __popcll(m_eq);
+                    if (need < 0) need = 0;
+                }
             }
         }
 
         // ---- write the new prediction (ascending columns) and push the change
         // of the statistics (:290-293 minus :243-246) to memory ----
+        XC_STAMP(3); // top-k
         bool any_change = false;
 #pragma unroll
         for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
@@ -268,6 +367,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                     p_eta[slot] = cur.eta[c];
                 }
                 base += __popcll(mask);
+                if (lane + XC_WAVE * c < r && in_new[c] != (cur.sel[c] != 0))
+                    P.sel[s0 + lane + XC_WAVE * c] = in_new[c] ? 1 : 0;
                 if (lane + XC_WAVE * c < r) {
                     double *st = P.state + (int64_t)cur.idx[c] * XC_STATE_STRIDE;
                     const double ed = (double)cur.eta[c];
@@ -292,12 +393,23 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // gathers statistics for its next row
         if (P.n_waves == 1) __builtin_amdgcn_s_waitcnt(0);
 
+        XC_STAMP(4); // stores + atomics
         // ---- rotate the pipeline ----
         cur = nxt;
         row0 = row1; s0 = s1; e0 = e1;
         row1 = row2; s1 = s2; e1 = e2;
         row2 = row3;
+#ifdef XC_STAMPS
+        // the rotation consumes the prefetched registers: wait for them here so the
+        // stamp prices it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        XC_STAMP(5); // prefetch landing
     }
+#ifdef XC_STAMPS
+    if (P.stamps && lane == 0)
+        for (int i = 0; i < XC_NSTAMP; ++i) atomicAdd(P.stamps + i, st_sum[i]);
+#endif
     if (P.changed && lane == 0 && n_changed)
         atomicAdd(P.changed, n_changed);
 }
@@ -306,7 +418,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 template <typename T>
 __global__ __launch_bounds__(XC_BLOCK) void gather_pred_eta_kernel(
     int64_t n_k, int k, const int32_t *indptr, const int32_t *indices, const T *data,
-    const int32_t *pred_indices, T *pred_eta) {
+    const int32_t *pred_indices, T *pred_eta, uint8_t *sel, int32_t *orphans) {
     const int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
     if (t >= n_k) return;
     const int64_t row = t / k;
@@ -317,9 +429,10 @@ __global__ __launch_bounds__(XC_BLOCK) void gather_pred_eta_kernel(
         if (indices[mid] < col) lo = mid + 1;
         else hi = mid;
     }
-    T v = (T)0;
-    if (lo < indptr[row + 1] && indices[lo] == col) v = data[lo];
-    pred_eta[t] = v;
+    const bool found = lo < indptr[row + 1] && indices[lo] == col;
+    pred_eta[t] = found ? data[lo] : (T)0;
+    if (found && sel) sel[lo] = 1;
+    if (orphans) orphans[t] = found ? -1 : col;
 }
 
 // ---- s = column sums of y_proba ------------------------------------------------
@@ -414,6 +527,8 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
     tn[j] = skip_tn ? -1.0 : (n_counted - st[1] - st[2]);
 }
 
+static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
+
 template <typename T, bool EXACT, bool HAS_ORDER>
 static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
     const int blocks = (P.n_waves + 3) / 4;
@@ -452,7 +567,8 @@ static int grid_for(int64_t n_items) {
 extern "C" {
 
 int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
-                           int dtype, const int32_t *pred_indices, int k, void *pred_eta, void *stream) {
+                           int dtype, const int32_t *pred_indices, int k, void *pred_eta, uint8_t *sel,
+                           int32_t *orphans, void *stream) {
     if (n < 0 || k < 1 || (n > 0 && (!indptr || !pred_indices || !pred_eta)))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_gather_pred_eta: bad argument");
     if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_gather_pred_eta: unknown dtype %d", dtype);
@@ -462,10 +578,10 @@ int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indi
     hipStream_t st = xc::as_stream(stream);
     if (dtype == XC_F32)
         hipLaunchKernelGGL((xc::gather_pred_eta_kernel<float>), dim3(blocks), dim3(XC_BLOCK), 0, st, n_k, k, indptr, indices,
-                           static_cast<const float *>(data), pred_indices, static_cast<float *>(pred_eta));
+                           static_cast<const float *>(data), pred_indices, static_cast<float *>(pred_eta), sel, orphans);
     else
         hipLaunchKernelGGL((xc::gather_pred_eta_kernel<double>), dim3(blocks), dim3(XC_BLOCK), 0, st, n_k, k, indptr, indices,
-                           static_cast<const double *>(data), pred_indices, static_cast<double *>(pred_eta));
+                           static_cast<const double *>(data), pred_indices, static_cast<double *>(pred_eta), sel, orphans);
     XC_CHECK_LAUNCH("gather_pred_eta_kernel");
     return XC_OK;
 }
@@ -544,10 +660,11 @@ int xc_utility_finish_host(const double *partials, double *out_host, void *strea
 
 int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz,
-                     int32_t *pred_indices, void *pred_eta, int k, double *state,
+                     int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
+                     double *state,
                      const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
                      int64_t *changed, void *stream) {
-    if (n_order < 0 || n_norm < 1 || !indptr || !pred_indices || !pred_eta || !state || !metric_host)
+    if (n_order < 0 || n_norm < 1 || !indptr || !pred_indices || !pred_eta || !sel || !state || !metric_host)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
     if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_sweep_csr: k=%d outside 1..%d", k, XC_MAX_K);
     if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: unknown dtype %d", dtype);
@@ -562,18 +679,25 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
     hipStream_t st = xc::as_stream(stream);
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
-                                 static_cast<float *>(pred_eta), k, state, *metric_host, (double)n_norm,
+                                 static_cast<float *>(pred_eta), sel, orphans, k, state, *metric_host, (double)n_norm,
                                  1.0 / (double)n_norm, (double)n_norm, maximize, greedy, skip_tn, n_waves,
-                                 reinterpret_cast<unsigned long long *>(changed)};
+                                 reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<float>(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
-                                  static_cast<double *>(pred_eta), k, state, *metric_host, (double)n_norm,
+                                  static_cast<double *>(pred_eta), sel, orphans, k, state, *metric_host, (double)n_norm,
                                   1.0 / (double)n_norm, (double)n_norm, maximize, greedy, skip_tn, n_waves,
-                                  reinterpret_cast<unsigned long long *>(changed)};
+                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<double>(P, ch, st);
     }
     XC_CHECK_LAUNCH("bca_sweep_csr_kernel");
+    return XC_OK;
+}
+
+// Diagnostic builds (-DXC_STAMPS) only: device buffer of 8 uint64 phase-cycle sums.
+// Not part of include/xcolumns_amd.h; the shipped library ignores the pointer.
+int xc_debug_set_stamp_buffer(void *buf) {
+    xc::g_stamp_buffer = static_cast<unsigned long long *>(buf);
     return XC_OK;
 }
 

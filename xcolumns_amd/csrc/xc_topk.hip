@@ -29,6 +29,7 @@ struct TopkParams {
     int32_t *out_indices;
     T *out_data;
     T *out_eta;
+    uint8_t *out_sel;
     int n_waves;
 };
 
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
                 if (o_eta) o_eta[slot] = eta[c];
             }
             base += __popcll(mask);
+            if (P.out_sel && lane + XC_WAVE * c < r) P.out_sel[s + lane + XC_WAVE * c] = sel[c] ? 1 : 0;
         }
         // :599-601: slots a short row leaves unused keep column 0 / value 1
         if (lane >= n_sel && lane < k) {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
 template <typename T>
 static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
                        int k, const void *a, const void *b, int keep_scores, int32_t *out_indices,
-                       void *out_data, void *out_eta, int ch, hipStream_t st) {
+                       void *out_data, void *out_eta, uint8_t *out_sel, int ch, hipStream_t st) {
     TopkParams<T> P;
     P.n = n;
     P.indptr = indptr;
@@ -162,6 +164,7 @@ static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices,
     P.out_indices = out_indices;
     P.out_data = static_cast<T *>(out_data);
     P.out_eta = static_cast<T *>(out_eta);
+    P.out_sel = out_sel;
     P.n_waves = default_row_waves(n);
     const int blocks = (P.n_waves + 3) / 4;
     switch (ch) {
@@ -180,7 +183,7 @@ extern "C" {
 
 int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data, int dtype,
                 int max_row_nnz, int k, const void *a, const void *b, int keep_scores,
-                int32_t *out_indices, void *out_data, void *out_eta, void *stream) {
+                int32_t *out_indices, void *out_data, void *out_eta, uint8_t *out_sel, void *stream) {
     if (n < 0 || !indptr || (n > 0 && (!out_indices || !out_data)))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr: NULL pointer or negative n");
     if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_topk_csr: k=%d outside 1..%d", k, XC_MAX_K);
@@ -191,9 +194,9 @@ int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const 
     if (n == 0) return XC_OK;
     hipStream_t st = xc::as_stream(stream);
     if (dtype == XC_F32)
-        xc::launch_topk<float>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, ch, st);
+        xc::launch_topk<float>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
     else
-        xc::launch_topk<double>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, ch, st);
+        xc::launch_topk<double>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
     XC_CHECK_LAUNCH("topk_csr_kernel");
     return XC_OK;
 }

@@ -26,9 +26,10 @@ from .types import DenseMatrix, DType, Matrix, is_dense, is_matrix
 
 def topk_csr_device(csr: D.DeviceCSR, k: int, a: Optional[torch.Tensor] = None,
                     b: Optional[torch.Tensor] = None, keep_scores: bool = False,
-                    want_eta: bool = False):
+                    want_eta: bool = False, out_sel: Optional[torch.Tensor] = None):
     """``xc_topk_csr`` on a device-resident CSR matrix.  Returns
-    (indices[n*k] int32, data[n*k], eta[n*k] or None)."""
+    (indices[n*k] int32, data[n*k], eta[n*k] or None); `out_sel` (uint8 per stored
+    entry) is filled with the chosen-entry flags when given."""
     n = csr.n
     dev = csr.data.device
     out_idx = torch.empty(n * k, dtype=torch.int32, device=dev)
@@ -36,7 +37,7 @@ def topk_csr_device(csr: D.DeviceCSR, k: int, a: Optional[torch.Tensor] = None,
     out_eta = torch.empty(n * k, dtype=csr.data.dtype, device=dev) if want_eta else None
     _lib.call("xc_topk_csr", n, D.ptr(csr.indptr), D.ptr(csr.indices), D.ptr(csr.data), csr.code,
               int(csr.max_row_nnz), int(k), D.ptr(a), D.ptr(b), int(bool(keep_scores)),
-              D.ptr(out_idx), D.ptr(out_dat), D.ptr(out_eta), D.stream())
+              D.ptr(out_idx), D.ptr(out_dat), D.ptr(out_eta), D.ptr(out_sel), D.stream())
     return out_idx, out_dat, out_eta
 
 
