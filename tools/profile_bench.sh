@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# rocprofv3 runs of bench.py on the GPU box: kernel trace + stats, then two PMC
+# passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).  Summaries
+# land in gpurun_out/prof_*; copy what is judged into profiles/.
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out
+TAG=${1:-c2}
+shift || true
+ARGS="$*"
+mkdir -p $OUT
+cd $R
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_trace -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_trace.log 2>&1 || { echo "trace run failed"; tail -5 $OUT/prof_${TAG}_trace.log; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_fetch.log 2>&1 || { echo "fetch run failed"; tail -5 $OUT/prof_${TAG}_fetch.log; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_write.log 2>&1 || { echo "write run failed"; tail -5 $OUT/prof_${TAG}_write.log; exit 1; }
+find $OUT/prof_${TAG}_trace $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write -type f | head -30

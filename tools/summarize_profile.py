@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (tools/profile_bench.sh) into a small text summary
+for profiles/: per-kernel stats, the timed sweeps' average duration, and the
+FETCH_SIZE / WRITE_SIZE counters per launch (raw KB and bytes).
+
+    python tools/summarize_profile.py gpurun_out c2 [timed_steps] > profiles/r01_c2_summary.txt
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+base, tag = sys.argv[1], sys.argv[2]
+timed = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+
+
+def one(pattern):
+    files = glob.glob(os.path.join(base, pattern), recursive=True)
+    return files[0] if files else None
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+print(f"# rocprofv3 summary, tag={tag} (python3 bench.py --no-cpu-baseline; MI355X gfx950)")
+f = one(f"prof_{tag}_trace/**/*_kernel_stats.csv")
+if f:
+    print("\n## kernel stats (--kernel-trace --stats), all launches incl. setup and warm-up")
+    print(f"{'kernel':72s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for row in csv.DictReader(open(f)):
+        print(f"{short(row['Name']):72s} {row['Calls']:>6s} {float(row['AverageNs']) / 1e3:10.2f} "
+              f"{float(row['MinNs']) / 1e3:10.2f} {float(row['MaxNs']) / 1e3:10.2f} {float(row['Percentage']):6.2f}")
+f = one(f"prof_{tag}_trace/**/*_kernel_trace.csv")
+if f:
+    rows = [r for r in csv.DictReader(open(f)) if "bca_sweep_csr_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    last = durs[-timed:]
+    print(f"\n## bca_sweep_csr_kernel launches in order (us): {[round(d, 1) for d in durs]}")
+    print(f"timed region = last {len(last)} launches: average {sum(last) / len(last):.2f} us "
+          f"(compare with roofline.avg_kernel_ms of the bench line)")
+    if rows:
+        r = rows[-1]
+        print(f"grid={r.get('Grid_Size')} workgroup={r.get('Workgroup_Size')} vgpr={r.get('VGPR_Count')} "
+              f"sgpr={r.get('SGPR_Count')} lds={r.get('LDS_Block_Size')} scratch={r.get('Scratch_Size')}")
+for ctr in ("fetch", "write"):
+    f = one(f"prof_{tag}_{ctr}/**/*_counter_collection.csv")
+    if not f:
+        continue
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        per[(short(r["Kernel_Name"]), r["Counter_Name"])].append((int(r["Start_Timestamp"]), float(r["Counter_Value"])))
+    print(f"\n## --pmc {ctr.upper()}_SIZE per launch (counter unit: KB; bytes = value * 1024)")
+    for (k, c), vals in sorted(per.items()):
+        vals.sort()
+        v = [x[1] for x in vals]
+        tail = v[-timed:] if "bca_sweep" in k else v
+        print(f"{k:72s} {c:11s} launches={len(v):3d} avg_KB={sum(tail) / len(tail):12.1f} "
+              f"avg_MB={sum(tail) / len(tail) * 1024 / 1e6:9.2f}" + ("  (timed launches)" if "bca_sweep" in k else ""))
