@@ -27,11 +27,14 @@ for step in "$@"; do
         bench) run bench 600 python bench.py ;;
         bench_zipf) run bench_zipf 600 python bench.py --zipf --no-cpu-baseline ;;
         bench_ns) run bench_ns 900 python bench.py --workload ns_1Mx500K --no-cpu-baseline ;;
+        bench_c3) run bench_c3 900 python bench.py --workload c3_amazon670k_150Kx670K --no-cpu-baseline ;;
+        e2e) run e2e 600 python tools/e2e_api_timing.py ;;
+        drift_ns) run drift_ns 900 python tools/drift_study.py 400000 200000 ;;
         *) echo "unknown step $step" ;;
     esac
 done
 cat gpurun_out/session.log
-for f in probe smoke gpu_tests bench bench_zipf bench_ns; do
+for f in probe smoke gpu_tests bench bench_zipf bench_ns bench_c3 e2e drift_ns; do
     [ -f gpurun_out/$f.log ] && { echo "--- $f (tail)"; tail -25 gpurun_out/$f.log; }
 done
 exit 0

@@ -203,6 +203,9 @@ class BcaCsrEngine:
         if n_order >= c.n:
             self.orphans = None
 
+    def reset_changed(self):
+        self.changed.zero_()
+
     def rows_changed(self) -> int:
         """Rows whose prediction changed since `changed` was zeroed (all ranks)."""
         if self.comm is not None:
@@ -244,6 +247,53 @@ class _OrderSource:
 # ---------------------------------------------------------------------------
 # predict_using_bc_with_0approx
 # ---------------------------------------------------------------------------
+
+def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, metric_aggregation: str,
+                   maximize: bool, tolerance: float, max_iters: int, greedy: bool, policy, verbose: bool,
+                   meta: Dict[str, Any]) -> None:
+    """The sweep loop of predict_using_bc_with_0approx (block_coordinate.py:415-493)
+    over an engine that holds this rank's rows: order -> (recompute, utility) ->
+    sweep -> recompute, utility -> stopping rule.  `eng` is a :class:`BcaCsrEngine`
+    (or anything with its methods: the multi-rank CPU tests inject a checker-backed
+    one); with sharded rows every rank runs this loop and reaches the same decision
+    because utilities come from all-reduced statistics."""
+    changed_prev = None
+    new_utility = None
+    new_utility_sum = None
+    for j in range(1, max_iters + 1):
+        log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
+        order = next_order()
+        if j == 1:
+            eng.reset_state(greedy)
+        if greedy:
+            # all four vectors are zeros, tn included (:423-427)
+            old_utility = eng.utility_sum(n_u, n_counted=0.0, skip_tn=False)
+        elif new_utility is None:
+            log_info("    Calculating expected confusion matrix ...", verbose)
+            old_utility = eng.recompute_utility_sum(n_u)
+        else:
+            # the end-of-sweep recompute of sweep j-1 IS the start-of-sweep one of j (:430, :465)
+            old_utility = new_utility_sum
+        if metric_aggregation == "mean":
+            old_utility = old_utility / m
+
+        log_info("    Doing block coordinate optimization steps ...", verbose)
+        eng.reset_changed()
+        eng.sweep(order, n_order, policy.next(changed_prev), greedy=greedy)
+        if greedy:
+            eng.sync_column_sums()
+        new_utility_sum = eng.recompute_utility_sum(n_u)
+        changed_prev = eng.rows_changed()
+        new_utility = new_utility_sum / m if metric_aggregation == "mean" else new_utility_sum
+
+        greedy = False
+        meta["iters"] = j
+        meta["utilities"].append(new_utility)
+        log_info(f"    Iteration {j}/{max_iters} finished, expected metric value: {old_utility} -> {new_utility}", verbose)
+        if (maximize and new_utility - old_utility < tolerance) or (not maximize and new_utility - old_utility > tolerance):
+            log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
+            break
+
 
 def _initial_csr_indices(y_proba: csr_matrix, init_y_pred, k: int, seed) -> Optional[np.ndarray]:
     """block_coordinate.py:28-51 for CSR input; None means "top" (done on the GPU)."""
@@ -294,41 +344,8 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
 
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
     policy = WavePolicy(n_u, fixed=bca_waves)
-    changed_prev = None
-    new_utility = None
-    for j in range(1, max_iters + 1):
-        log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
-        order = orders.next()
-        if j == 1:
-            eng.reset_state(greedy)
-        if greedy:
-            # all four vectors are zeros, tn included (:423-427)
-            old_utility = eng.utility_sum(n_u, n_counted=0.0, skip_tn=False)
-        elif new_utility is None:
-            log_info("    Calculating expected confusion matrix ...", verbose)
-            old_utility = eng.recompute_utility_sum(n_u)
-        else:
-            # the end-of-sweep recompute of sweep j-1 IS the start-of-sweep one of j (:430, :465)
-            old_utility = new_utility_sum
-        if metric_aggregation == "mean":
-            old_utility = old_utility / m
-
-        log_info("    Doing block coordinate optimization steps ...", verbose)
-        eng.changed.zero_()
-        eng.sweep(order, n_u, policy.next(changed_prev), greedy=greedy)
-        if greedy:
-            eng.sync_column_sums()
-        new_utility_sum = eng.recompute_utility_sum(n_u)
-        changed_prev = eng.rows_changed()
-        new_utility = new_utility_sum / m if metric_aggregation == "mean" else new_utility_sum
-
-        greedy = False
-        meta["iters"] = j
-        meta["utilities"].append(new_utility)
-        log_info(f"    Iteration {j}/{max_iters} finished, expected metric value: {old_utility} -> {new_utility}", verbose)
-        if (maximize and new_utility - old_utility < tolerance) or (not maximize and new_utility - old_utility > tolerance):
-            log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
-            break
+    run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
+                   policy, verbose, meta)
 
     new_indices = eng.pred_idx.cpu().numpy()
     if isinstance(init_y_pred, csr_matrix):

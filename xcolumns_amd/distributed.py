@@ -60,3 +60,90 @@ def local_order(global_order: np.ndarray, lo: int, hi: int) -> np.ndarray:
     row block, kept in the global order, rebased to local row ids."""
     sel = global_order[(global_order >= lo) & (global_order < hi)]
     return (sel - lo).astype(np.int32)
+
+
+def predict_bca_csr_sharded(
+    y_proba_shard: csr_matrix,
+    binary_metric_func,
+    k: int,
+    comm: TorchComm,
+    metric_aggregation: str = "mean",
+    metric_kwargs=None,
+    maximize: bool = True,
+    tolerance: float = 1e-6,
+    max_iters: int = 100,
+    shuffle_order: bool = True,
+    skip_tn: bool = False,
+    seed: Optional[int] = None,
+    verbose: bool = False,
+    bca_waves: Optional[int] = None,
+    engine_factory=None,
+):
+    """BCA (init "top") with the rows sharded over the ranks of `comm`: every rank
+    passes ITS contiguous block of rows and gets back the prediction for them
+    (csr_matrix) plus the meta dict, identical on all ranks.
+
+    The global visiting order is the reference's stream
+    (``np.random.default_rng(seed)``, block_coordinate.py:413-419) over the global
+    row ids, restricted to the rank's block (:func:`local_order`).
+    `engine_factory(csr_shard, k, gain_spec, utility_spec, maximize, skip_tn, n_total,
+    comm)` builds the per-rank engine; the default is the GPU engine."""
+    from time import time
+
+    from . import block_coordinate as bc
+    from .metrics import resolve_metric
+
+    if not isinstance(k, int):
+        raise ValueError("k must be an integer")
+    n_local, m = y_proba_shard.shape
+    counts = torch.zeros(comm.world, dtype=torch.int64)
+    counts[comm.rank] = n_local
+    if engine_factory is None:
+        from . import _device as D
+        dev = D.require_gpu()
+        counts = counts.to(dev)
+    comm.all_reduce(counts)
+    counts = counts.cpu().numpy()
+    lo = int(counts[:comm.rank].sum())
+    hi = lo + n_local
+    n_total = int(counts.sum())
+
+    gain_spec = resolve_metric(binary_metric_func, metric_kwargs)
+    utility_spec = resolve_metric(binary_metric_func, None)
+    if engine_factory is None:
+        csr = D.DeviceCSR.from_scipy(y_proba_shard, dev)
+        eng = bc.BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
+                              n_total=n_total, comm=comm)
+        to_dev = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    else:
+        eng = engine_factory(y_proba_shard, k, gain_spec, utility_spec, maximize, skip_tn, n_total, comm)
+        to_dev = lambda a: a  # noqa: E731
+    eng.init_top()
+
+    rng = np.random.default_rng(seed)
+    order = np.arange(n_total)
+
+    def next_order():
+        if not shuffle_order:
+            return None
+        rng.shuffle(order)
+        return to_dev(local_order(order, lo, hi))
+
+    meta = {"utilities": [], "iters": 0, "time": time()}
+    policy = bc.WavePolicy(n_local, fixed=bca_waves) if engine_factory is None else _FixedWaves(bca_waves or 1)
+    bc.run_bca_sweeps(eng, next_order, n_local, n_total, m, metric_aggregation, maximize, tolerance, max_iters,
+                      False, policy, verbose, meta)
+    meta["time"] = time() - meta["time"]
+    idx = eng.pred_idx.cpu().numpy() if isinstance(eng.pred_idx, torch.Tensor) else np.asarray(eng.pred_idx)
+    out_indptr = (np.arange(n_local + 1, dtype=np.int64) * k).astype(y_proba_shard.indptr.dtype)
+    y_pred = csr_matrix((np.ones(n_local * k, dtype=y_proba_shard.dtype),
+                         idx.astype(y_proba_shard.indices.dtype, copy=False), out_indptr), shape=(n_local, m))
+    return y_pred, meta
+
+
+class _FixedWaves:
+    def __init__(self, w):
+        self.w = int(w)
+
+    def next(self, changed_prev=None):
+        return self.w
