@@ -70,12 +70,14 @@ typedef struct xc_metric {
     double mf;      /* number of labels, for the mixed utilities */
 } xc_metric;
 
-/* Per-label BCA statistics, one 32-byte record per label (see DESIGN.md "data
- * layout"): {tp, fp, s, spare} as float64 where s = tp + fn is the column sum
- * of y_proba over the rows counted so far.  fn and tn are derived:
- *   fn = s - tp,  tn = n_counted - fp - s.
- * One record = one 32-byte sector, so a candidate label costs one gather. */
-#define XC_STATE_STRIDE 4 /* doubles per label */
+/* Per-label BCA statistics (see DESIGN.md "data layout"):
+ *   tpfp    float64[m][2]  one 16-byte record {tp, fp} per label: a candidate label
+ *                          costs ONE 16-byte gather in the sweep;
+ *   colsum  float64[m]     s = tp + fn = column sum of y_proba over the rows counted
+ *                          so far (constant during a non-greedy sweep);
+ *   s_entry float64[nnz]   colsum expanded per stored entry of y_proba, so it
+ *                          streams in with the row instead of being gathered.
+ * fn and tn are derived: fn = s - tp, tn = n_counted - fp - s. */
 
 /* ---- library / device -------------------------------------------------- */
 
@@ -157,10 +159,14 @@ int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indi
                            int k, void *pred_eta, uint8_t *sel, int32_t *orphans,
                            void *stream);
 
-/* state[j].s += column sums of y_proba over its nnz stored entries (one-off;
- * state zeroed by the caller). */
+/* colsum[j] += sum of the stored entries of column j (one-off per run; colsum
+ * zeroed by the caller; all-reduce it when the rows are sharded). */
 int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data,
-                      int dtype, double *state, void *stream);
+                      int dtype, double *colsum, void *stream);
+
+/* s_entry[p] = colsum[indices[p]] for every stored entry p. */
+int xc_bca_expand_colsum(int64_t nnz, const int32_t *indices, const double *colsum,
+                         double *s_entry, void *stream);
 
 /* Expected tp / fp of the current prediction, from scratch:
  *   acc[j*2+0] += eta, acc[j*2+1] += (1 - eta) for every predicted (row, j)
@@ -172,15 +178,14 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices,
                            const void *pred_eta, int dtype, double *acc,
                            void *stream);
 
-/* state[j].tp, state[j].fp <- acc[j] and, in the same pass, the per-label metric
- * values of _calculate_utility (block_coordinate.py:54-90) on
- * (tp/n, fp/n, fn/n, tn/n) with fn = s - tp and tn = n_counted - fp - s
- * (tn = -1 when skip_tn, confusion_matrix.py:391-393), reduced to
- * partials[XC_UTILITY_PARTIALS] in a fixed order.  acc may be NULL (evaluate the
- * state as it stands). */
+/* tpfp[j] <- acc[j] and, in the same pass, the per-label metric values of
+ * _calculate_utility (block_coordinate.py:54-90) on (tp/n, fp/n, fn/n, tn/n) with
+ * fn = s - tp and tn = n_counted - fp - s (tn = -1 when skip_tn,
+ * confusion_matrix.py:391-393), reduced to partials[XC_UTILITY_PARTIALS] in a
+ * fixed order.  acc may be NULL (evaluate tpfp as it stands). */
 #define XC_UTILITY_PARTIALS 1024
 int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted,
-                          const double *acc, double *state,
+                          const double *acc, double *tpfp, const double *colsum,
                           const xc_metric *metric_host, int skip_tn,
                           double *partials, void *stream);
 /* Blocking: waits for `stream`, sums the partials in index order on the host and
@@ -199,7 +204,10 @@ int xc_utility_finish_host(const double *partials, double *out_host, void *strea
  *                row does not store; they leave the prediction when the row is
  *                visited (pass it for the first sweep after a foreign
  *                initialisation, NULL afterwards)
- *   state        per-label records, updated with float64 atomics
+ *   m            number of labels
+ *   tpfp/colsum  per-label statistics, updated with float64 atomics
+ *   s_entry      colsum per stored entry (xc_bca_expand_colsum); may be NULL when
+ *                greedy (colsum is then gathered and grows during the sweep)
  *   greedy       first sweep of init_y_pred="greedy": rows are added as they are
  *                visited (:243 skipped, stats start from zero)
  *   n_waves      number of wavefronts that walk `order` concurrently: wave w takes
@@ -211,14 +219,15 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      const int32_t *indptr, const int32_t *indices, const void *data,
                      int dtype, int max_row_nnz, int32_t *pred_indices,
                      void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     double *state,
+                     int64_t m, double *tpfp, double *colsum, const double *s_entry,
                      const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
-/* Unpack the per-label records into the reference's four vectors
+/* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */
-int xc_bca_state_unpack(int64_t m, const double *state, double n_counted, int skip_tn,
-                        double *tp, double *fp, double *fn, double *tn, void *stream);
+int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum,
+                        double n_counted, int skip_tn, double *tp, double *fp, double *fn,
+                        double *tn, void *stream);
 
 /* ---- block coordinate ascent, dense ------------------------------------ */
 

@@ -19,7 +19,6 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 XC_F32, XC_F64 = 0, 1
 XC_MAX_K = 64
 XC_MAX_ROW_NNZ = 1024
-XC_STATE_STRIDE = 4
 XC_UTILITY_PARTIALS = 1024
 XC_ERR_BAD_ARG, XC_ERR_K_RANGE, XC_ERR_ROW_TOO_LONG, XC_ERR_NO_DEVICE = -1, -2, -3, -4
 
@@ -62,15 +61,17 @@ SIGNATURES = {
     "xc_bca_gather_pred_eta": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_colsum_csr": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "xc_bca_expand_colsum": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_accumulate_pred": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "xc_bca_commit_utility": (c_int, [c_int64, c_int64, c_double, c_void_p, c_void_p,
+    "xc_bca_commit_utility": (c_int, [c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p,
                                       POINTER(XcMetric), c_int, c_void_p, c_void_p]),
     "xc_utility_finish_host": (c_int, [c_void_p, POINTER(c_double), c_void_p]),
     "xc_bca_sweep_csr": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, POINTER(XcMetric),
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
+                                 c_void_p, c_void_p, POINTER(XcMetric),
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "xc_bca_state_unpack": (c_int, [c_int64, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p]),
+    "xc_bca_state_unpack": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
     "xc_bca_sweep_dense": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                    c_int, c_void_p, c_void_p, POINTER(XcMetric), c_int, c_int, c_int,
                                    c_void_p]),

@@ -98,10 +98,11 @@ class BcaCsrEngine:
     """Device-resident state of one BCA run over CSR rows held by THIS rank.
 
     HBM layout (DESIGN.md): CSR y_proba (int32 indptr/indices, f32|f64 data);
-    prediction as fixed-stride ``pred_idx[n*k]`` + ``pred_eta[n*k]``; per-label
-    records ``state[m][4] = {tp, fp, s, spare}`` float64; ``acc[m][2]`` float64 for
-    the from-scratch tp/fp of every sweep boundary (the all-reduce payload when
-    rows are sharded over ranks).
+    prediction as fixed-stride ``pred_idx[n*k]`` + ``pred_eta[n*k]`` plus one byte per
+    stored entry (``sel``); per-label records ``tpfp[m][2] = {tp, fp}`` float64,
+    ``colsum[m]`` (s = tp + fn) and its per-entry expansion ``s_entry[nnz]``;
+    ``acc[m][2]`` float64 for the from-scratch tp/fp of every sweep boundary (the
+    all-reduce payload when rows are sharded over ranks).
     """
 
     def __init__(self, csr: D.DeviceCSR, k: int, gain_spec: MetricSpec, utility_spec: MetricSpec,
@@ -120,7 +121,9 @@ class BcaCsrEngine:
         dev = csr.data.device
         self.dev = dev
         m = csr.m
-        self.state = torch.zeros((m, _lib.XC_STATE_STRIDE), dtype=torch.float64, device=dev)
+        self.tpfp = torch.zeros((m, 2), dtype=torch.float64, device=dev)
+        self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
+        self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
         self.acc = torch.zeros((m, 2), dtype=torch.float64, device=dev)
         self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS, dtype=torch.float64, device=dev)
         self.changed = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -151,21 +154,29 @@ class BcaCsrEngine:
 
     # -- statistics -------------------------------------------------------------
     def reset_state(self, greedy: bool):
-        """Zero the records; unless `greedy`, s <- column sums of y_proba (all ranks)."""
-        self.state.zero_()
+        """Zero the statistics; unless `greedy`, colsum <- column sums of y_proba over
+        all ranks, expanded per stored entry."""
+        self.tpfp.zero_()
+        self.colsum.zero_()
         if not greedy:
             c = self.csr
             _lib.call("xc_bca_colsum_csr", c.nnz, D.ptr(c.indices), D.ptr(c.data), c.code,
-                      D.ptr(self.state), D.stream())
+                      D.ptr(self.colsum), D.stream())
             if self.comm is not None:
-                self.comm.all_reduce(self.state)
+                self.comm.all_reduce(self.colsum)
+            self._expand_colsum()
+
+    def _expand_colsum(self):
+        c = self.csr
+        _lib.call("xc_bca_expand_colsum", c.nnz, D.ptr(c.indices), D.ptr(self.colsum), D.ptr(self.s_entry),
+                  D.stream())
 
     def sync_column_sums(self):
-        """After a greedy sweep on sharded rows: s holds this rank's rows only."""
+        """After a greedy sweep: colsum holds this rank's rows only -> all ranks;
+        then expand it for the following (non-greedy) sweeps."""
         if self.comm is not None:
-            s = self.state[:, 2].contiguous()
-            self.comm.all_reduce(s)
-            self.state[:, 2] = s
+            self.comm.all_reduce(self.colsum)
+        self._expand_colsum()
 
     def recompute_utility_sum(self, n_norm_utility: int) -> float:
         """calculate_confusion_matrix(y_proba, y_pred) + _calculate_utility
@@ -183,7 +194,8 @@ class BcaCsrEngine:
                     skip_tn: Optional[bool] = None) -> float:
         _lib.call("xc_bca_commit_utility", self.csr.m, int(n_norm_utility),
                   float(self.n_total if n_counted is None else n_counted),
-                  D.ptr(self.acc) if commit else None, D.ptr(self.state), ctypes.byref(self.utility_metric),
+                  D.ptr(self.acc) if commit else None, D.ptr(self.tpfp), D.ptr(self.colsum),
+                  ctypes.byref(self.utility_metric),
                   int(self.skip_tn if skip_tn is None else skip_tn), D.ptr(self.partials), D.stream())
         out = ctypes.c_double(0.0)
         _lib.call("xc_utility_finish_host", D.ptr(self.partials), ctypes.byref(out), D.stream())
@@ -196,8 +208,8 @@ class BcaCsrEngine:
         c = self.csr
         _lib.call("xc_bca_sweep_csr", int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx),
-                  D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(self.orphans), self.k, D.ptr(self.state),
-                  ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
+                  D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(self.orphans), self.k, int(c.m), D.ptr(self.tpfp),
+                  D.ptr(self.colsum), D.ptr(self.s_entry), ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
                   int(n_waves), D.ptr(self.changed), D.stream())
         # every row was visited: no orphan is left in any prediction
         if n_order >= c.n:
@@ -216,7 +228,7 @@ class BcaCsrEngine:
         """(tp, fp, fn, tn) float64 tensors on the GPU, the reference's four vectors."""
         m = self.csr.m
         out = torch.empty((4, m), dtype=torch.float64, device=self.dev)
-        _lib.call("xc_bca_state_unpack", m, D.ptr(self.state), float(self.n_total), int(self.skip_tn),
+        _lib.call("xc_bca_state_unpack", m, D.ptr(self.tpfp), D.ptr(self.colsum), float(self.n_total), int(self.skip_tn),
                   D.ptr(out[0]), D.ptr(out[1]), D.ptr(out[2]), D.ptr(out[3]), D.stream())
         return out
 

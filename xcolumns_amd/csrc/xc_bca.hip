@@ -6,12 +6,16 @@
 // numba_sub_from_/add_to_unnormalized_confusion_matrix_csr
 // (numba_csr_functions.py:385-452) and numba_set_gains_csr (:499-546).
 //
-// Data layout.  Per label j one 32-byte record {tp, fp, s, spare} (float64),
-// s = tp + fn = column sum of y_proba over the rows counted so far.  One
-// candidate label = one 32-byte sector gathered from L2 / Infinity Cache
-// instead of three 8-byte gathers from three vectors.  fn = s - tp and
-// tn = n_counted - fp - s are derived in registers, so a change of prediction
-// touches only tp and fp (two adjacent float64 atomics = one 16-byte request).
+// Data layout.  Per label j one 16-byte record {tp, fp} (float64) in `tpfp`: one
+// candidate label = ONE 16-byte gather (buffer_load_dwordx4 sc1) from L2 /
+// Infinity Cache instead of three 8-byte gathers from three vectors -- the sweep
+// is bound by the number of scattered L2 requests per row, not by bytes.  The
+// third statistic is carried as s = tp + fn = the column sum of y_proba over the
+// rows counted so far (`colsum`, float64 per label): it does not change during a
+// sweep, so it is expanded once per run into `s_entry`, one float64 per STORED
+// ENTRY of y_proba, and streams in with the row (coalesced) instead of being
+// gathered.  fn = s - tp and tn = n_counted - fp - s are derived in registers, so
+// a change of prediction touches only tp and fp (two adjacent float64 atomics).
 //
 // One wavefront per row.  "Remove the row's contribution" (:243-246) is done in
 // registers on the gathered values instead of by atomics on memory, and "add it
@@ -41,10 +45,13 @@ struct SweepParams {
     uint8_t *sel;           // per stored entry of y_proba: 1 = currently predicted
     const int32_t *orphans; // optional [n*k]: predicted columns the row does not store, -1 = none
     int k;
-    double *state;
-    xc_metric metric;
-    double nn;        // divisor n of the step (block_coordinate.py:229-231)
-    double inv_nn;    // 1 / nn, used by the non-exact arithmetic
+    double *tpfp;           // [m][2] float64 records {tp, fp}
+    double *colsum;         // [m] s = tp + fn
+    const double *s_entry;  // [nnz] colsum expanded per stored entry (NULL in the greedy sweep)
+    unsigned tpfp_bytes;
+    xc_metric metric;      // as given (EXACT path)
+    xc_metric metric_fast; // epsilon * n, kf * n: evaluates the raw statistics (non-exact path)
+    double nn;             // divisor n of the step (block_coordinate.py:229-231)
     double n_counted; // rows counted in the statistics when not greedy
     int maximize;
     int greedy;
@@ -76,23 +83,25 @@ __device__ __forceinline__ unsigned long long sortable_key(double g) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// x / nn: the reference divides (block_coordinate.py:252-264).  EXACT keeps the
-// IEEE division (bit-identical gains, used by the sequential mode that must
-// reproduce the reference's trajectory); otherwise one multiply by 1/nn -- the
-// gains move by <= 1 ulp, far inside the 1e-5 utility tolerance of the
-// concurrent mode, and the per-row critical path loses six divisions.
-template <bool EXACT>
-__device__ __forceinline__ double div_n(double x, double nn, double inv_nn) {
-    return EXACT ? x / nn : x * inv_nn;
-}
-
+// Normalisation by n (block_coordinate.py:252-264).  EXACT divides every entry by
+// n like the reference (bit-identical gains; the sequential mode that must
+// reproduce the reference's trajectory).  The concurrent mode skips it: every
+// metric here is a ratio of the entries, so psi(x / n; eps, k) = psi(x; eps * n,
+// k * n) -- the host passes the rescaled constants in `metric_fast` and the
+// kernel feeds the raw statistics, saving six divisions per candidate.
 // The row a wavefront works on: everything that does not depend on the
 // statistics, so it can be fetched ahead of time.
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+#define XC_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
+#define XC_CPOL_SC1 16           /* cache policy bit 4 = sc1 on gfx94x/gfx950 */
+
 template <typename T, int CH>
 struct RowData {
     int idx[CH];
     T eta[CH];
     uint8_t sel[CH]; // is the entry in the row's current prediction
+    double sc[CH];   // column sum of the entry's label (s_entry), non-greedy sweeps
 };
 
 // All lanes load (clamped to the row's last entry): straight-line code keeps the
@@ -107,6 +116,7 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
         d.idx[c] = P.indices[s + pc];
         d.eta[c] = P.data[s + pc];
         d.sel[c] = P.sel[s + pc];
+        d.sc[c] = P.s_entry ? P.s_entry[s + pc] : 0.0;
     }
 }
 
@@ -161,11 +171,12 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
     if (wave >= P.n_waves) return;
     const int k = P.k;
-    const double nn = P.nn, inv_nn = P.inv_nn;
+    const double nn = P.nn;
     const bool greedy = P.greedy != 0;
     const bool skip_tn = P.skip_tn != 0;
     const int64_t W = P.n_waves;
     const int64_t last = P.n_order - 1;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.tpfp, 0, P.tpfp_bytes, XC_RSRC_WORD3);
     unsigned long long n_changed = 0;
 
     // Software pipeline over the wave's positions pos, pos+W, pos+2W, ...:
@@ -178,9 +189,12 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         return HAS_ORDER ? P.order[q] : (int)q; // compile-time: no branch around the load
     };
     int64_t pos = wave;
-    int row0 = row_at(pos), row1 = row_at(pos + W), row2 = row_at(pos + 2 * W);
-    int s0 = P.indptr[row0], e0 = P.indptr[row0 + 1];
-    int s1 = P.indptr[row1], e1 = P.indptr[row1 + 1];
+    // row ids and row bounds are the same in all lanes: readfirstlane moves them to
+    // scalar registers, so row addresses are SGPR base + lane offset
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    int row0 = uni(row_at(pos)), row1 = uni(row_at(pos + W)), row2 = uni(row_at(pos + 2 * W));
+    int s0 = uni(P.indptr[row0]), e0 = uni(P.indptr[row0 + 1]);
+    int s1 = uni(P.indptr[row1]), e1 = uni(P.indptr[row1 + 1]);
     RowData<T, CH> cur;
     load_row<T, CH>(P, s0, e0 - s0, lane, cur);
 
@@ -192,14 +206,17 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         int32_t *p_idx = P.pred_indices + row * k;
         T *p_eta = P.pred_eta + row * k;
 
-        // ---- gather the statistics of the candidate labels (sc1 loads) ----
+        // ---- gather the statistics of the candidate labels: one 16-byte
+        // {tp, fp} record per candidate, agent-coherent (sc1: served by L2, never by
+        // this CU's L1, so other waves' atomics are seen) ----
         double tp[CH], fp[CH], sc[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const double *st = P.state + (int64_t)cur.idx[c] * XC_STATE_STRIDE;
-            tp[c] = load_coherent(st + 0);
-            fp[c] = load_coherent(st + 1);
-            sc[c] = greedy ? load_coherent(st + 2) : st[2];
+            const uint4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1);
+            const double2_t rec = __builtin_bit_cast(double2_t, raw);
+            tp[c] = rec.x;
+            fp[c] = rec.y;
+            sc[c] = greedy ? load_coherent(P.colsum + cur.idx[c]) : cur.sc[c];
         }
 
         // ---- prefetch for the following rows (issued AFTER the gathers so the
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         }
         if (P.orphans && !greedy && lane < k) {
             const int oid = P.orphans[row * k + lane];
-            if (oid >= 0) atomic_add_f64(P.state + (int64_t)oid * XC_STATE_STRIDE + 1, -1.0);
+            if (oid >= 0) atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
         }
         XC_STAMP(1); // membership
         // ---- gains (block_coordinate.py:248-282) ----
@@ -246,23 +263,34 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                 const double fn = scc - tpc;
                 const double n1 = greedy ? (double)pos : (P.n_counted - 1.0); // rows counted besides this one
                 const double tn = n1 - fpc - scc;
-                // :252-264
-                const double pos_tp = div_n<EXACT>(tpc + ed, nn, inv_nn);
-                const double pos_fp = div_n<EXACT>(fpc + omd, nn, inv_nn);
-                const double neg_fn = div_n<EXACT>(fn + ed, nn, inv_nn);
-                const double neg_tp = div_n<EXACT>(tpc, nn, inv_nn);
-                const double neg_fp = div_n<EXACT>(fpc, nn, inv_nn);
-                const double pos_fn = div_n<EXACT>(fn, nn, inv_nn);
-                // skip_tn: Etn is the constant -1, undivided (:260-261); zeros in the
-                // greedy first sweep (:427)
-                double pos_tn = greedy ? 0.0 : -1.0, neg_tn = pos_tn;
-                if (!skip_tn) {
-                    neg_tn = div_n<EXACT>(tn + omd, nn, inv_nn);
-                    pos_tn = div_n<EXACT>(tn, nn, inv_nn);
+                double g;
+                if (EXACT) {
+                    // :252-264
+                    const double pos_tp = (tpc + ed) / nn;
+                    const double pos_fp = (fpc + omd) / nn;
+                    const double neg_fn = (fn + ed) / nn;
+                    const double neg_tp = tpc / nn;
+                    const double neg_fp = fpc / nn;
+                    const double pos_fn = fn / nn;
+                    // skip_tn: Etn is the constant -1, undivided (:260-261); zeros in the
+                    // greedy first sweep (:427)
+                    double pos_tn = greedy ? 0.0 : -1.0, neg_tn = pos_tn;
+                    if (!skip_tn) {
+                        neg_tn = (tn + omd) / nn;
+                        pos_tn = tn / nn;
+                    }
+                    // :267-282
+                    g = metric_eval_t<true>(P.metric, pos_tp, pos_fp, pos_fn, pos_tn) -
+                        metric_eval_t<true>(P.metric, neg_tp, neg_fp, neg_fn, neg_tn);
+                } else {
+                    double pos_tn = greedy ? 0.0 : -nn, neg_tn = pos_tn; // -1 * n
+                    if (!skip_tn) {
+                        neg_tn = tn + omd;
+                        pos_tn = tn;
+                    }
+                    g = metric_eval_t<false>(P.metric_fast, tpc + ed, fpc + omd, fn, pos_tn) -
+                        metric_eval_t<false>(P.metric_fast, tpc, fpc, fn + ed, neg_tn);
                 }
-                // :267-282
-                double g = metric_eval(P.metric, pos_tp, pos_fp, pos_fn, pos_tn) -
-                           metric_eval(P.metric, neg_tp, neg_fp, neg_fn, neg_tn);
                 if (!P.maximize) g = -g;
                 key[c] = sortable_key(nan_to_neg_inf(g));
             }
@@ -289,8 +317,15 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                     if (in_new[c]) lmin = key[c] < lmin ? key[c] : lmin;
                     else lmax = key[c] > lmax ? key[c] : lmax; // key 0 = no candidate
                 }
-                const unsigned long long smin = wave_umin64(lmin);
-                const unsigned long long umax = wave_umax64(lmax);
+                // high words first: they almost always decide; low words only when
+                // the two boundary keys share their high word
+                const unsigned smin_hi = wave_umin32((unsigned)(lmin >> 32));
+                const unsigned umax_hi = wave_umax32((unsigned)(lmax >> 32));
+                if (umax_hi < smin_hi) break;
+                const unsigned smin_lo = wave_umin32((unsigned)(lmin >> 32) == smin_hi ? (unsigned)lmin : ~0u);
+                const unsigned umax_lo = wave_umax32((unsigned)(lmax >> 32) == umax_hi ? (unsigned)lmax : 0u);
+                const unsigned long long smin = ((unsigned long long)smin_hi << 32) | smin_lo;
+                const unsigned long long umax = ((unsigned long long)umax_hi << 32) | umax_lo;
                 if (umax < smin) break;
                 int n_min = 0, n_max = 0;
 #pragma unroll
@@ -370,11 +405,11 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                 if (lane + XC_WAVE * c < r && in_new[c] != (cur.sel[c] != 0))
                     P.sel[s0 + lane + XC_WAVE * c] = in_new[c] ? 1 : 0;
                 if (lane + XC_WAVE * c < r) {
-                    double *st = P.state + (int64_t)cur.idx[c] * XC_STATE_STRIDE;
+                    double *st = P.tpfp + (int64_t)cur.idx[c] * 2;
                     const double ed = (double)cur.eta[c];
                     const double omd = (double)((T)1 - cur.eta[c]);
                     if (greedy) {
-                        atomic_add_f64(st + 2, ed);
+                        atomic_add_f64(P.colsum + cur.idx[c], ed);
                         if (in_new[c]) {
                             atomic_add_f64(st + 0, ed);
                             atomic_add_f64(st + 1, omd);
@@ -397,8 +432,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // ---- rotate the pipeline ----
         cur = nxt;
         row0 = row1; s0 = s1; e0 = e1;
-        row1 = row2; s1 = s2; e1 = e2;
-        row2 = row3;
+        row1 = row2; s1 = uni(s2); e1 = uni(e2);
+        row2 = uni(row3);
 #ifdef XC_STAMPS
         // the rotation consumes the prefetched registers: wait for them here so the
         // stamp prices it
@@ -438,10 +473,18 @@ __global__ __launch_bounds__(XC_BLOCK) void gather_pred_eta_kernel(
 // ---- s = column sums of y_proba ------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(XC_BLOCK) void colsum_csr_kernel(int64_t nnz, const int32_t *indices,
-                                                              const T *data, double *state) {
+                                                              const T *data, double *colsum) {
     const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride)
-        atomic_add_f64(state + (int64_t)indices[t] * XC_STATE_STRIDE + 2, (double)data[t]);
+        atomic_add_f64(colsum + indices[t], (double)data[t]);
+}
+
+// s_entry[p] = colsum[indices[p]]: the column sum carried next to every stored entry
+__global__ __launch_bounds__(XC_BLOCK) void expand_colsum_kernel(int64_t nnz, const int32_t *indices,
+                                                                 const double *colsum, double *s_entry) {
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride)
+        s_entry[t] = colsum[indices[t]];
 }
 
 // ---- tp / fp of the current prediction from scratch ------------------------------
@@ -462,27 +505,26 @@ __global__ __launch_bounds__(XC_BLOCK) void accumulate_pred_kernel(int64_t n_k, 
 // each; the strip sum is a fixed-shape LDS tree, so the partials (and their
 // in-order host sum) do not depend on timing.
 __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, double nn, double n_counted,
-                                                                  const double *acc, double *state,
-                                                                  xc_metric metric, int skip_tn,
-                                                                  double *partials) {
+                                                                  const double *acc, double *tpfp,
+                                                                  const double *colsum, xc_metric metric,
+                                                                  int skip_tn, double *partials) {
     __shared__ double red[XC_BLOCK];
     const int64_t per = (m + XC_UTILITY_PARTIALS - 1) / XC_UTILITY_PARTIALS;
     const int64_t j0 = (int64_t)blockIdx.x * per;
     const int64_t j1 = (j0 + per < m) ? j0 + per : m;
     double sum = 0.0;
     for (int64_t j = j0 + threadIdx.x; j < j1; j += XC_BLOCK) {
-        double *st = state + j * XC_STATE_STRIDE;
         double tp, fp;
         if (acc) {
             tp = acc[2 * j];
             fp = acc[2 * j + 1];
-            st[0] = tp;
-            st[1] = fp;
+            tpfp[2 * j] = tp;
+            tpfp[2 * j + 1] = fp;
         } else {
-            tp = st[0];
-            fp = st[1];
+            tp = tpfp[2 * j];
+            fp = tpfp[2 * j + 1];
         }
-        const double sc = st[2];
+        const double sc = colsum[j];
         const double fn = sc - tp;
         // confusion_matrix.py:391-397; _calculate_utility gets Etn / n (:438-445)
         const double tn = skip_tn ? -1.0 : (n_counted - fp - sc);
@@ -515,16 +557,15 @@ __global__ __launch_bounds__(XC_BLOCK) void utility_vectors_kernel(int64_t m, do
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const double *state, double n_counted,
-                                                                int skip_tn, double *tp, double *fp, double *fn,
-                                                                double *tn) {
+__global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const double *tpfp, const double *colsum,
+                                                                double n_counted, int skip_tn, double *tp, double *fp,
+                                                                double *fn, double *tn) {
     const int64_t j = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
     if (j >= m) return;
-    const double *st = state + j * XC_STATE_STRIDE;
-    tp[j] = st[0];
-    fp[j] = st[1];
-    fn[j] = st[2] - st[0];
-    tn[j] = skip_tn ? -1.0 : (n_counted - st[1] - st[2]);
+    tp[j] = tpfp[2 * j];
+    fp[j] = tpfp[2 * j + 1];
+    fn[j] = colsum[j] - tpfp[2 * j];
+    tn[j] = skip_tn ? -1.0 : (n_counted - tpfp[2 * j + 1] - colsum[j]);
 }
 
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
@@ -586,9 +627,9 @@ int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indi
     return XC_OK;
 }
 
-int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data, int dtype, double *state,
+int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data, int dtype, double *colsum,
                       void *stream) {
-    if (nnz < 0 || (nnz > 0 && (!indices || !data || !state)))
+    if (nnz < 0 || (nnz > 0 && (!indices || !data || !colsum)))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_colsum_csr: bad argument");
     if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_colsum_csr: unknown dtype %d", dtype);
     if (nnz == 0) return XC_OK;
@@ -596,11 +637,21 @@ int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data, int
     const int blocks = xc::grid_for(nnz);
     if (dtype == XC_F32)
         hipLaunchKernelGGL((xc::colsum_csr_kernel<float>), dim3(blocks), dim3(XC_BLOCK), 0, st, nnz, indices,
-                           static_cast<const float *>(data), state);
+                           static_cast<const float *>(data), colsum);
     else
         hipLaunchKernelGGL((xc::colsum_csr_kernel<double>), dim3(blocks), dim3(XC_BLOCK), 0, st, nnz, indices,
-                           static_cast<const double *>(data), state);
+                           static_cast<const double *>(data), colsum);
     XC_CHECK_LAUNCH("colsum_csr_kernel");
+    return XC_OK;
+}
+
+int xc_bca_expand_colsum(int64_t nnz, const int32_t *indices, const double *colsum, double *s_entry, void *stream) {
+    if (nnz < 0 || (nnz > 0 && (!indices || !colsum || !s_entry)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_expand_colsum: bad argument");
+    if (nnz == 0) return XC_OK;
+    hipLaunchKernelGGL(xc::expand_colsum_kernel, dim3(xc::grid_for(nnz)), dim3(XC_BLOCK), 0, xc::as_stream(stream), nnz,
+                       indices, colsum, s_entry);
+    XC_CHECK_LAUNCH("expand_colsum_kernel");
     return XC_OK;
 }
 
@@ -622,14 +673,15 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices, const void 
     return XC_OK;
 }
 
-int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, const double *acc, double *state,
-                          const xc_metric *metric_host, int skip_tn, double *partials, void *stream) {
-    if (m < 0 || n_norm < 1 || !state || !metric_host || !partials)
+int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, const double *acc, double *tpfp,
+                          const double *colsum, const xc_metric *metric_host, int skip_tn, double *partials,
+                          void *stream) {
+    if (m < 0 || n_norm < 1 || !tpfp || !colsum || !metric_host || !partials)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: bad argument");
     if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: unknown metric %d", metric_host->base);
     hipLaunchKernelGGL(xc::commit_utility_kernel, dim3(XC_UTILITY_PARTIALS), dim3(XC_BLOCK), 0, xc::as_stream(stream), m,
-                       (double)n_norm, n_counted, acc, state, *metric_host, skip_tn, partials);
+                       (double)n_norm, n_counted, acc, tpfp, colsum, *metric_host, skip_tn, partials);
     XC_CHECK_LAUNCH("commit_utility_kernel");
     return XC_OK;
 }
@@ -661,11 +713,16 @@ int xc_utility_finish_host(const double *partials, double *out_host, void *strea
 int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz,
                      int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     double *state,
+                     int64_t m, double *tpfp, double *colsum, const double *s_entry,
                      const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
                      int64_t *changed, void *stream) {
-    if (n_order < 0 || n_norm < 1 || !indptr || !pred_indices || !pred_eta || !sel || !state || !metric_host)
+    if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
+        !metric_host)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
+    if (!greedy && !s_entry)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: s_entry is required unless greedy");
+    if (m > (int64_t)(0xFFFFFFFFu / 16))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: m too large for 32-bit record offsets");
     if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_sweep_csr: k=%d outside 1..%d", k, XC_MAX_K);
     if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: unknown dtype %d", dtype);
     if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
@@ -677,16 +734,21 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
     if (n_order == 0) return XC_OK;
     if (n_waves > n_order) n_waves = (int)n_order;
     hipStream_t st = xc::as_stream(stream);
+    xc_metric fast = *metric_host; // psi(x / n; eps, k) = psi(x; eps * n, k * n)
+    fast.epsilon *= (double)n_norm;
+    fast.kf *= (double)n_norm;
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
-                                 static_cast<float *>(pred_eta), sel, orphans, k, state, *metric_host, (double)n_norm,
-                                 1.0 / (double)n_norm, (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry,
+                                 (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                 (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<float>(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
-                                  static_cast<double *>(pred_eta), sel, orphans, k, state, *metric_host, (double)n_norm,
-                                  1.0 / (double)n_norm, (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry,
+                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                  (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<double>(P, ch, st);
     }
@@ -701,13 +763,14 @@ int xc_debug_set_stamp_buffer(void *buf) {
     return XC_OK;
 }
 
-int xc_bca_state_unpack(int64_t m, const double *state, double n_counted, int skip_tn, double *tp, double *fp,
-                        double *fn, double *tn, void *stream) {
-    if (m < 0 || !state || !tp || !fp || !fn || !tn) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_state_unpack: bad argument");
+int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum, double n_counted, int skip_tn,
+                        double *tp, double *fp, double *fn, double *tn, void *stream) {
+    if (m < 0 || !tpfp || !colsum || !tp || !fp || !fn || !tn)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_state_unpack: bad argument");
     if (m == 0) return XC_OK;
     const int blocks = (int)((m + XC_BLOCK - 1) / XC_BLOCK);
-    hipLaunchKernelGGL(xc::state_unpack_kernel, dim3(blocks), dim3(XC_BLOCK), 0, xc::as_stream(stream), m, state, n_counted,
-                       skip_tn, tp, fp, fn, tn);
+    hipLaunchKernelGGL(xc::state_unpack_kernel, dim3(blocks), dim3(XC_BLOCK), 0, xc::as_stream(stream), m, tpfp, colsum,
+                       n_counted, skip_tn, tp, fp, fn, tn);
     XC_CHECK_LAUNCH("state_unpack_kernel");
     return XC_OK;
 }
