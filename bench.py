@@ -132,7 +132,6 @@ def main():
     def step(s, timed):
         """One BCA iteration exactly as predict_using_bc_with_0approx runs it."""
         n_waves = policy.next(state["changed"])
-        eng.changed.zero_()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

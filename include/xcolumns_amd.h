@@ -171,9 +171,10 @@ int xc_bca_expand_colsum(int64_t nnz, const int32_t *indices, const double *cols
 /* Expected tp / fp of the current prediction, from scratch:
  *   acc[j*2+0] += eta, acc[j*2+1] += (1 - eta) for every predicted (row, j)
  * -- the tp and fp passes of calculate_confusion_matrix(y_proba, y_pred)
- * (block_coordinate.py:430-436, :465-467); fn follows from s.  acc: float64
- * [m*2], accumulated into (zero first; all-reduce it across ranks when the rows
- * are sharded). */
+ * (block_coordinate.py:430-436); fn follows from s.  acc: float64 [2m (+1)],
+ * accumulated into (zero first; all-reduce it across ranks when the rows are
+ * sharded).  Needed for the initial statistics only: later sweeps fill acc
+ * themselves (xc_bca_sweep_csr). */
 int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices,
                            const void *pred_eta, int dtype, double *acc,
                            void *stream);
@@ -182,15 +183,20 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices,
  * _calculate_utility (block_coordinate.py:54-90) on (tp/n, fp/n, fn/n, tn/n) with
  * fn = s - tp and tn = n_counted - fp - s (tn = -1 when skip_tn,
  * confusion_matrix.py:391-393), reduced to partials[XC_UTILITY_PARTIALS] in a
- * fixed order.  acc may be NULL (evaluate tpfp as it stands). */
+ * fixed order.  acc may be NULL (evaluate tpfp as it stands).  With acc:
+ * partials[XC_UTILITY_PARTIALS] <- acc[2m] (the changed-row count the sweep left
+ * there) and, when clear_acc, acc is zeroed for the next sweep.
+ * partials: float64[XC_UTILITY_PARTIALS + 1]. */
 #define XC_UTILITY_PARTIALS 1024
-int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted,
-                          const double *acc, double *tpfp, const double *colsum,
+int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, double *acc,
+                          int clear_acc, double *tpfp, const double *colsum,
                           const xc_metric *metric_host, int skip_tn,
                           double *partials, void *stream);
 /* Blocking: waits for `stream`, sums the partials in index order on the host and
- * writes the sum to *out_host (divide by m for "mean"). */
-int xc_utility_finish_host(const double *partials, double *out_host, void *stream);
+ * writes the sum to *out_host (divide by m for "mean"); *out_extra_host (optional)
+ * receives partials[XC_UTILITY_PARTIALS]. */
+int xc_utility_finish_host(const double *partials, double *out_host,
+                           double *out_extra_host, void *stream);
 
 /* One sweep of block_coordinate.py:448-463 with _bc_with_0approx_step_csr
  * (:212-293) as the body, for k > 0 and rows holding >= k entries.
@@ -208,6 +214,11 @@ int xc_utility_finish_host(const double *partials, double *out_host, void *strea
  *   tpfp/colsum  per-label statistics, updated with float64 atomics
  *   s_entry      colsum per stored entry (xc_bca_expand_colsum); may be NULL when
  *                greedy (colsum is then gathered and grows during the sweep)
+ *   acc          optional float64[2m + 1], zeroed by the caller: the sweep adds every
+ *                visited row's NEW prediction into it ({tp, fp} per label) -- when
+ *                all rows are visited this IS the sweep-boundary recompute
+ *                (block_coordinate.py:465-467), no second pass -- and the number of
+ *                changed rows into acc[2m]
  *   greedy       first sweep of init_y_pred="greedy": rows are added as they are
  *                visited (:243 skipped, stats start from zero)
  *   n_waves      number of wavefronts that walk `order` concurrently: wave w takes
@@ -220,7 +231,7 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      int dtype, int max_row_nnz, int32_t *pred_indices,
                      void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
                      int64_t m, double *tpfp, double *colsum, const double *s_entry,
-                     const xc_metric *metric_host, int maximize, int greedy,
+                     double *acc, const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
 /* Unpack the per-label statistics into the reference's four vectors

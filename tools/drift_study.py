@@ -53,14 +53,13 @@ for waves in sorted({1, max(1, n // 4096), max(1, n // 1024), max(1, n // 256), 
     eng.recompute_utility_sum(n)
     us, ms, ch = [], [], []
     for s in range(sweeps):
-        eng.changed.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         eng.sweep(orders[s], n, waves)
         e1.record()
         us.append(eng.recompute_utility_sum(n) / m)
         ms.append(e0.elapsed_time(e1))
-        ch.append(int(eng.changed.item()))
+        ch.append(eng.rows_changed())
     d = np.abs(np.asarray(us) - uo)
     rows.append(dict(waves=waves, frac=waves / n, diff=d.tolist(), sweep_ms=ms, changed=ch))
     print(f"waves={waves:6d} ({waves / n:.4%}) diff={np.array2string(d, precision=2)} "

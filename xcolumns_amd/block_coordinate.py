@@ -124,8 +124,11 @@ class BcaCsrEngine:
         self.tpfp = torch.zeros((m, 2), dtype=torch.float64, device=dev)
         self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
         self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
-        self.acc = torch.zeros((m, 2), dtype=torch.float64, device=dev)
-        self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS, dtype=torch.float64, device=dev)
+        # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count
+        self.acc = torch.zeros(2 * m + 1, dtype=torch.float64, device=dev)
+        self._acc_filled = False    # did the last sweep leave the new prediction's statistics in acc
+        self._changed_last = 0
+        self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=dev)
         self.changed = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pred_idx: Optional[torch.Tensor] = None
         self.pred_eta: Optional[torch.Tensor] = None
@@ -180,49 +183,67 @@ class BcaCsrEngine:
 
     def recompute_utility_sum(self, n_norm_utility: int) -> float:
         """calculate_confusion_matrix(y_proba, y_pred) + _calculate_utility
-        (block_coordinate.py:430-445 / :465-476): tp, fp from scratch (one
-        all-reduce of 2m doubles when sharded), then the sum over labels of the
-        binary metric on the normalised entries.  Blocks on the result."""
-        self.acc.zero_()
-        _lib.call("xc_bca_accumulate_pred", self.csr.n * self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
-                  self.csr.code, D.ptr(self.acc), D.stream())
+        (block_coordinate.py:430-445 / :465-476): tp, fp of the current prediction from
+        scratch (one all-reduce of 2m+1 doubles when sharded), then the sum over labels
+        of the binary metric on the normalised entries.  A sweep that visited every
+        row has already accumulated them (xc_bca_sweep_csr `acc`); otherwise one pass
+        over the prediction does.  Blocks on the result."""
+        if not self._acc_filled:
+            self.acc.zero_()
+            _lib.call("xc_bca_accumulate_pred", self.csr.n * self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
+                      self.csr.code, D.ptr(self.acc), D.stream())
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
+        self._acc_filled = False
         return self.utility_sum(n_norm_utility, commit=True)
 
     def utility_sum(self, n_norm_utility: int, commit: bool = False, n_counted: Optional[float] = None,
                     skip_tn: Optional[bool] = None) -> float:
         _lib.call("xc_bca_commit_utility", self.csr.m, int(n_norm_utility),
                   float(self.n_total if n_counted is None else n_counted),
-                  D.ptr(self.acc) if commit else None, D.ptr(self.tpfp), D.ptr(self.colsum),
+                  D.ptr(self.acc) if commit else None, 1, D.ptr(self.tpfp), D.ptr(self.colsum),
                   ctypes.byref(self.utility_metric),
                   int(self.skip_tn if skip_tn is None else skip_tn), D.ptr(self.partials), D.stream())
-        out = ctypes.c_double(0.0)
-        _lib.call("xc_utility_finish_host", D.ptr(self.partials), ctypes.byref(out), D.stream())
+        out, extra = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _lib.call("xc_utility_finish_host", D.ptr(self.partials), ctypes.byref(out), ctypes.byref(extra), D.stream())
+        if commit:
+            self._changed_last = int(round(extra.value))
         return out.value
 
     # -- one sweep ------------------------------------------------------------------
     def sweep(self, order: Optional[torch.Tensor], n_order: int, n_waves: int, greedy: bool = False):
         """block_coordinate.py:448-463 over `order` (int32 row ids on the GPU, or
-        None for 0..n_order-1)."""
+        None for 0..n_order-1).  When every row is visited the kernel also leaves the
+        new prediction's from-scratch statistics in `acc` (zero on entry: the commit
+        kernel clears it)."""
         c = self.csr
+        full = n_order >= c.n
+        if not full:
+            self.changed.zero_()
         _lib.call("xc_bca_sweep_csr", int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx),
                   D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(self.orphans), self.k, int(c.m), D.ptr(self.tpfp),
-                  D.ptr(self.colsum), D.ptr(self.s_entry), ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
-                  int(n_waves), D.ptr(self.changed), D.stream())
+                  D.ptr(self.colsum), D.ptr(self.s_entry), D.ptr(self.acc) if full else None,
+                  ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
+                  int(n_waves), None if full else D.ptr(self.changed), D.stream())
+        self._acc_filled = full
+        self._partial_sweep = not full
         # every row was visited: no orphan is left in any prediction
-        if n_order >= c.n:
+        if full:
             self.orphans = None
 
     def reset_changed(self):
-        self.changed.zero_()
+        """Kept for engine-interface compatibility: counters are reset by the kernels."""
+        self._partial_sweep = False
 
     def rows_changed(self) -> int:
-        """Rows whose prediction changed since `changed` was zeroed (all ranks)."""
-        if self.comm is not None:
-            self.comm.all_reduce(self.changed)
-        return int(self.changed.item())
+        """Rows whose prediction changed in the last sweep, over all ranks (read after
+        recompute_utility_sum: the count travels with the statistics)."""
+        if getattr(self, "_partial_sweep", False):
+            if self.comm is not None:
+                self.comm.all_reduce(self.changed)
+            return int(self.changed.item())
+        return self._changed_last
 
     def confusion_vectors(self):
         """(tp, fp, fn, tn) float64 tensors on the GPU, the reference's four vectors."""
@@ -386,7 +407,7 @@ def _dense_utility(stats: torch.Tensor, n_u: int, metric_c, partials: torch.Tens
     m = stats.shape[1]
     _lib.call("xc_utility_vectors", m, int(n_u), D.ptr(stats), ctypes.byref(metric_c), D.ptr(partials), D.stream())
     out = ctypes.c_double(0.0)
-    _lib.call("xc_utility_finish_host", D.ptr(partials), ctypes.byref(out), D.stream())
+    _lib.call("xc_utility_finish_host", D.ptr(partials), ctypes.byref(out), None, D.stream())
     return out.value
 
 
@@ -424,7 +445,7 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
     gain_c, util_c = gain_spec.to_c(), utility_spec.to_c()
     stats = torch.zeros((4, m), dtype=torch.float64, device=dev)
     work = torch.empty(m, dtype=torch.float64, device=dev)
-    partials = torch.zeros(_lib.XC_UTILITY_PARTIALS, dtype=torch.float64, device=dev)
+    partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=dev)
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
     for j in range(1, max_iters + 1):
         log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)

@@ -48,6 +48,8 @@ struct SweepParams {
     double *tpfp;           // [m][2] float64 records {tp, fp}
     double *colsum;         // [m] s = tp + fn
     const double *s_entry;  // [nnz] colsum expanded per stored entry (NULL in the greedy sweep)
+    double *acc;            // optional [2m + 1]: from-scratch {tp, fp} of the NEW prediction, [2m] += changed rows
+    int64_t m;
     unsigned tpfp_bytes;
     xc_metric metric;      // as given (EXACT path)
     xc_metric metric_fast; // epsilon * n, kf * n: evaluates the raw statistics (non-exact path)
@@ -391,6 +393,19 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 #pragma unroll
         for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
         const bool row_changed = __ballot(any_change) != 0ull;
+        // The from-scratch recompute of the sweep boundary (block_coordinate.py:465-467:
+        // tp / fp of the new prediction summed over ALL rows) is accumulated here, row
+        // by row, instead of by a separate pass over the prediction afterwards.
+        if (P.acc) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (in_new[c]) {
+                    double *a = P.acc + (int64_t)cur.idx[c] * 2;
+                    atomic_add_f64(a + 0, (double)cur.eta[c]);
+                    atomic_add_f64(a + 1, (double)((T)1 - cur.eta[c]));
+                }
+            }
+        }
         if (row_changed || greedy) {
             int base = 0;
 #pragma unroll
@@ -445,8 +460,10 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     if (P.stamps && lane == 0)
         for (int i = 0; i < XC_NSTAMP; ++i) atomicAdd(P.stamps + i, st_sum[i]);
 #endif
-    if (P.changed && lane == 0 && n_changed)
-        atomicAdd(P.changed, n_changed);
+    if (lane == 0 && n_changed) {
+        if (P.changed) atomicAdd(P.changed, n_changed);
+        if (P.acc) atomic_add_f64(P.acc + 2 * P.m, (double)n_changed);
+    }
 }
 
 // ---- pred_eta lookup --------------------------------------------------------
@@ -505,7 +522,7 @@ __global__ __launch_bounds__(XC_BLOCK) void accumulate_pred_kernel(int64_t n_k, 
 // each; the strip sum is a fixed-shape LDS tree, so the partials (and their
 // in-order host sum) do not depend on timing.
 __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, double nn, double n_counted,
-                                                                  const double *acc, double *tpfp,
+                                                                  double *acc, int clear_acc, double *tpfp,
                                                                   const double *colsum, xc_metric metric,
                                                                   int skip_tn, double *partials) {
     __shared__ double red[XC_BLOCK];
@@ -520,6 +537,10 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
             fp = acc[2 * j + 1];
             tpfp[2 * j] = tp;
             tpfp[2 * j + 1] = fp;
+            if (clear_acc) {
+                acc[2 * j] = 0.0;
+                acc[2 * j + 1] = 0.0;
+            }
         } else {
             tp = tpfp[2 * j];
             fp = tpfp[2 * j + 1];
@@ -537,6 +558,10 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
         __syncthreads();
     }
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+    if (acc && blockIdx.x == 0 && threadIdx.x == 0) { // the changed-row count rides in acc[2m]
+        partials[XC_UTILITY_PARTIALS] = acc[2 * m];
+        if (clear_acc) acc[2 * m] = 0.0;
+    }
 }
 
 __global__ __launch_bounds__(XC_BLOCK) void utility_vectors_kernel(int64_t m, double nn, const double *stats,
@@ -673,7 +698,7 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices, const void 
     return XC_OK;
 }
 
-int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, const double *acc, double *tpfp,
+int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, double *acc, int clear_acc, double *tpfp,
                           const double *colsum, const xc_metric *metric_host, int skip_tn, double *partials,
                           void *stream) {
     if (m < 0 || n_norm < 1 || !tpfp || !colsum || !metric_host || !partials)
@@ -681,7 +706,7 @@ int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, const dou
     if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: unknown metric %d", metric_host->base);
     hipLaunchKernelGGL(xc::commit_utility_kernel, dim3(XC_UTILITY_PARTIALS), dim3(XC_BLOCK), 0, xc::as_stream(stream), m,
-                       (double)n_norm, n_counted, acc, tpfp, colsum, *metric_host, skip_tn, partials);
+                       (double)n_norm, n_counted, acc, clear_acc, tpfp, colsum, *metric_host, skip_tn, partials);
     XC_CHECK_LAUNCH("commit_utility_kernel");
     return XC_OK;
 }
@@ -698,22 +723,23 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats, const xc_
     return XC_OK;
 }
 
-int xc_utility_finish_host(const double *partials, double *out_host, void *stream) {
+int xc_utility_finish_host(const double *partials, double *out_host, double *out_extra_host, void *stream) {
     if (!partials || !out_host) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_utility_finish_host: NULL pointer");
-    double buf[XC_UTILITY_PARTIALS];
+    double buf[XC_UTILITY_PARTIALS + 1];
     hipStream_t st = xc::as_stream(stream);
     XC_HIP_TRY(hipMemcpyAsync(buf, partials, sizeof(buf), hipMemcpyDeviceToHost, st));
     XC_HIP_TRY(hipStreamSynchronize(st));
     double sum = 0.0;
     for (int i = 0; i < XC_UTILITY_PARTIALS; ++i) sum += buf[i];
     *out_host = sum;
+    if (out_extra_host) *out_extra_host = buf[XC_UTILITY_PARTIALS];
     return XC_OK;
 }
 
 int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz,
                      int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     int64_t m, double *tpfp, double *colsum, const double *s_entry,
+                     int64_t m, double *tpfp, double *colsum, const double *s_entry, double *acc,
                      const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
                      int64_t *changed, void *stream) {
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
@@ -739,14 +765,14 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
     fast.kf *= (double)n_norm;
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
-                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry,
+                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry, acc, m,
                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<float>(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
-                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry,
+                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry, acc, m,
                                   (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                   (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
