@@ -95,11 +95,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # XC_BENCH_BACKEND=gloo + XC_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow with
+    # several ranks on ONE GPU (RCCL refuses duplicate devices); never used for numbers.
+    one_device = os.environ.get("XC_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one_device else local_rank)
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=os.environ.get("XC_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
         comm = TorchComm()
 
     n, m = WORKLOADS[args.workload]
@@ -120,7 +123,7 @@ def main():
         rng.shuffle(order)
         orders[s] = torch.from_numpy(order.astype(np.int32)).to(dev)
 
-    policy = WavePolicy(n, fixed=args.waves if args.waves > 0 else None)
+    policy = WavePolicy(n, fixed=args.waves if args.waves > 0 else None, world=world)
     eng.init_top()
     eng.reset_state(greedy=False)
     u0 = eng.recompute_utility_sum(n_u) / m

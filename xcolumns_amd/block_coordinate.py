@@ -69,7 +69,11 @@ _MIN_WAVES = 16
 class WavePolicy:
     """Number of concurrent wavefronts for the next sweep."""
 
-    def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None):
+    def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None,
+                 world: int = 1):
+        """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows
+        (the changed-row count fed to :meth:`next` is the global one)."""
+        self.world = max(1, int(world))
         env = os.environ.get("XCOLUMNS_BCA_WAVES")
         self.fixed = int(fixed) if fixed else (int(env) if env else None)
         self.n = max(1, int(n_order))
@@ -80,7 +84,7 @@ class WavePolicy:
     def next(self, changed_prev: Optional[int] = None) -> int:
         if self.fixed:
             return max(1, min(self.fixed, self.n))
-        changed = self.n / 2 if changed_prev is None else max(1, int(changed_prev))
+        changed = self.n / 2 if changed_prev is None else max(1.0, changed_prev / self.world)
         want = int(self.budget * self.n * self.n / changed)
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
 

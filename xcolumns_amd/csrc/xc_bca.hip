@@ -298,6 +298,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             }
         }
 
+        XC_STAMP(2); // wait for the gathers + gains
         // ---- top-k (numba_set_gains_csr -> numba_argtopk_csr,
         // numba_csr_functions.py:455-466, :514-524).
         // Fast path: start from the current prediction and swap its worst member
