@@ -179,6 +179,15 @@ def main():
     if rank == 0:
         b_step = algorithmic_bytes_per_row_step(R_NNZ, K)
         achieved = b_step * n / avg_sweep_s / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same
+        # command (tools/profile_bench.sh -> tools/summarize_profile.py), when present
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_zipf' if args.zipf else ''}.json")
+        if os.path.exists(tfile) and world == 1:
+            try:
+                traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "BCA iterations/sec x instances (rows/s) at k=5",
             "value": n * world * args.steps / elapsed,
@@ -207,7 +216,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_row": b_step,
                 "avg_kernel_ms": avg_sweep_s * 1e3,
             },

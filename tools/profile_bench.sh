@@ -14,4 +14,5 @@ cd $R
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_trace -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_trace.log 2>&1 || { echo "trace run failed"; tail -5 $OUT/prof_${TAG}_trace.log; exit 1; }
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_fetch.log 2>&1 || { echo "fetch run failed"; tail -5 $OUT/prof_${TAG}_fetch.log; exit 1; }
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_write.log 2>&1 || { echo "write run failed"; tail -5 $OUT/prof_${TAG}_write.log; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/prof_${TAG}_sq -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_sq.log 2>&1 || { echo "sq run failed"; tail -5 $OUT/prof_${TAG}_sq.log; exit 1; }
 find $OUT/prof_${TAG}_trace $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write -type f | head -30

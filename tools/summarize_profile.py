@@ -13,6 +13,9 @@ from collections import defaultdict
 
 base, tag = sys.argv[1], sys.argv[2]
 timed = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+traffic_json = sys.argv[4] if len(sys.argv) > 4 else None
+rows_per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else None
+sweep_bytes = {}
 
 
 def one(pattern):
@@ -60,3 +63,34 @@ for ctr in ("fetch", "write"):
         tail = v[-timed:] if "bca_sweep" in k else v
         print(f"{k:72s} {c:11s} launches={len(v):3d} avg_KB={sum(tail) / len(tail):12.1f} "
               f"avg_MB={sum(tail) / len(tail) * 1024 / 1e6:9.2f}" + ("  (timed launches)" if "bca_sweep" in k else ""))
+        if "bca_sweep" in k:
+            sweep_bytes[ctr] = sum(tail) / len(tail) * 1024
+
+f = one(f"prof_{tag}_sq/**/*_counter_collection.csv")
+if f:
+    per = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "bca_sweep" in r["Kernel_Name"]:
+            per[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+    print("\n## SQ counters of bca_sweep_csr_kernel, average over the timed launches"
+          + (f", per row ({rows_per_launch} rows per launch)" if rows_per_launch else ""))
+    for c, d in sorted(per.items()):
+        vals = [d[k] for k in sorted(d)][-timed:]
+        avg = sum(vals) / len(vals)
+        print(f"{c:24s} {avg:16.1f}" + (f"   per row {avg / rows_per_launch:10.1f}" if rows_per_launch else ""))
+
+if traffic_json and "fetch" in sweep_bytes and "write" in sweep_bytes:
+    import json
+    out = {
+        "kernel": "bca_sweep_csr_kernel",
+        "tag": tag,
+        "fetch_size_bytes_raw": sweep_bytes["fetch"],
+        "fetch_size_bytes_corrected": 2 * sweep_bytes["fetch"],
+        "write_size_bytes": sweep_bytes["write"],
+        "hbm_bytes_per_launch": 2 * sweep_bytes["fetch"] + sweep_bytes["write"],
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, average over the timed launches; "
+                "FETCH_SIZE doubled (gfx950 reports half of coalesced streams: MI355X_MICROARCH.md, confirmed on "
+                "colsum_csr_kernel: 40.0 MB read, 20.0 MB reported); counters include Infinity-Cache hits",
+    }
+    json.dump(out, open(traffic_json, "w"), indent=1)
+    print(f"\nwrote {traffic_json}")

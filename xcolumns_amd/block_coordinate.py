@@ -84,6 +84,10 @@ class WavePolicy:
     def next(self, changed_prev: Optional[int] = None) -> int:
         if self.fixed:
             return max(1, min(self.fixed, self.n))
+        if self.world > 1:
+            # rows of the other ranks are invisible within a sweep whatever W is
+            # (DESIGN.md section 7): bounding this rank's own concurrency buys nothing
+            return int(max(1, min(self.cap, self.n)))
         changed = self.n / 2 if changed_prev is None else max(1.0, changed_prev / self.world)
         want = int(self.budget * self.n * self.n / changed)
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
