@@ -20,7 +20,7 @@ sweep_bytes = {}
 
 def one(pattern):
     files = glob.glob(os.path.join(base, pattern), recursive=True)
-    return files[0] if files else None
+    return max(files, key=os.path.getmtime) if files else None  # newest run wins
 
 
 def short(name):
