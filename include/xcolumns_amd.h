@@ -77,6 +77,11 @@ typedef struct xc_metric {
  *                          so far (constant during a non-greedy sweep);
  *   s_entry float64[nnz]   colsum expanded per stored entry of y_proba, so it
  *                          streams in with the row instead of being gathered.
+ *   shadow  float32[m][2]  optional rounded copy of tpfp (8-byte records): what the
+ *                          CONCURRENT sweep gathers, so twice as many labels stay in
+ *                          an XCD's 4 MiB L2; written by xc_bca_commit_utility, kept
+ *                          in step by float32 atomics; the exact sequential sweep
+ *                          (n_waves == 1) and the greedy sweep read tpfp itself.
  * fn and tn are derived: fn = s - tp, tn = n_counted - fp - s. */
 
 /* ---- library / device -------------------------------------------------- */
@@ -189,7 +194,7 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices,
  * partials: float64[XC_UTILITY_PARTIALS + 1]. */
 #define XC_UTILITY_PARTIALS 1024
 int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, double *acc,
-                          int clear_acc, double *tpfp, const double *colsum,
+                          int clear_acc, double *tpfp, float *shadow, const double *colsum,
                           const xc_metric *metric_host, int skip_tn,
                           double *partials, void *stream);
 /* Blocking: waits for `stream`, sums the partials in index order on the host and
@@ -212,6 +217,7 @@ int xc_utility_finish_host(const double *partials, double *out_host,
  *                initialisation, NULL afterwards)
  *   m            number of labels
  *   tpfp/colsum  per-label statistics, updated with float64 atomics
+ *   shadow       optional float32 copy of tpfp (see above); NULL = gather tpfp
  *   s_entry      colsum per stored entry (xc_bca_expand_colsum); may be NULL when
  *                greedy (colsum is then gathered and grows during the sweep)
  *   acc          optional float64[2m + 1], zeroed by the caller: the sweep adds every
@@ -230,8 +236,8 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      const int32_t *indptr, const int32_t *indices, const void *data,
                      int dtype, int max_row_nnz, int32_t *pred_indices,
                      void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     int64_t m, double *tpfp, double *colsum, const double *s_entry,
-                     double *acc, const xc_metric *metric_host, int maximize, int greedy,
+                     int64_t m, double *tpfp, float *shadow, double *colsum,
+                     const double *s_entry, double *acc, const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
 /* Unpack the per-label statistics into the reference's four vectors

@@ -130,6 +130,9 @@ class BcaCsrEngine:
         self.dev = dev
         m = csr.m
         self.tpfp = torch.zeros((m, 2), dtype=torch.float64, device=dev)
+        # float32 copy of tpfp gathered by the concurrent sweep (XCOLUMNS_BCA_SHADOW=0 disables)
+        self.shadow = (torch.zeros((m, 2), dtype=torch.float32, device=dev)
+                       if os.environ.get("XCOLUMNS_BCA_SHADOW", "1") != "0" else None)
         self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
         self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
         # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count
@@ -168,6 +171,8 @@ class BcaCsrEngine:
         """Zero the statistics; unless `greedy`, colsum <- column sums of y_proba over
         all ranks, expanded per stored entry."""
         self.tpfp.zero_()
+        if self.shadow is not None:
+            self.shadow.zero_()
         self.colsum.zero_()
         if not greedy:
             c = self.csr
@@ -209,7 +214,7 @@ class BcaCsrEngine:
                     skip_tn: Optional[bool] = None) -> float:
         _lib.call("xc_bca_commit_utility", self.csr.m, int(n_norm_utility),
                   float(self.n_total if n_counted is None else n_counted),
-                  D.ptr(self.acc) if commit else None, 1, D.ptr(self.tpfp), D.ptr(self.colsum),
+                  D.ptr(self.acc) if commit else None, 1, D.ptr(self.tpfp), D.ptr(self.shadow), D.ptr(self.colsum),
                   ctypes.byref(self.utility_metric),
                   int(self.skip_tn if skip_tn is None else skip_tn), D.ptr(self.partials), D.stream())
         out, extra = ctypes.c_double(0.0), ctypes.c_double(0.0)
@@ -231,7 +236,7 @@ class BcaCsrEngine:
         _lib.call("xc_bca_sweep_csr", int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx),
                   D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(self.orphans), self.k, int(c.m), D.ptr(self.tpfp),
-                  D.ptr(self.colsum), D.ptr(self.s_entry), D.ptr(self.acc) if full else None,
+                  D.ptr(self.shadow), D.ptr(self.colsum), D.ptr(self.s_entry), D.ptr(self.acc) if full else None,
                   ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
                   int(n_waves), None if full else D.ptr(self.changed), D.stream())
         self._acc_filled = full

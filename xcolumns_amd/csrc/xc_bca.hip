@@ -45,7 +45,9 @@ struct SweepParams {
     uint8_t *sel;           // per stored entry of y_proba: 1 = currently predicted
     const int32_t *orphans; // optional [n*k]: predicted columns the row does not store, -1 = none
     int k;
-    double *tpfp;           // [m][2] float64 records {tp, fp}
+    double *tpfp;           // [m][2] float64 records {tp, fp} (master copy, atomics)
+    float *shadow;          // optional [m][2] float32 copy of tpfp: the gather target of the
+                            // concurrent sweep (8-byte records: twice the labels per L2 byte)
     double *colsum;         // [m] s = tp + fn
     const double *s_entry;  // [nnz] colsum expanded per stored entry (NULL in the greedy sweep)
     double *acc;            // optional [2m + 1]: from-scratch {tp, fp} of the NEW prediction, [2m] += changed rows
@@ -95,6 +97,8 @@ __device__ __forceinline__ unsigned long long sortable_key(double g) {
 // statistics, so it can be fetched ahead of time.
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 #define XC_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
 #define XC_CPOL_SC1 16           /* cache policy bit 4 = sc1 on gfx94x/gfx950 */
 
@@ -115,10 +119,12 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
     for (int c = 0; c < CH; ++c) {
         const int p = lane + XC_WAVE * c;
         const int pc = p < r ? p : r - 1;
-        d.idx[c] = P.indices[s + pc];
-        d.eta[c] = P.data[s + pc];
-        d.sel[c] = P.sel[s + pc];
-        d.sc[c] = P.s_entry ? P.s_entry[s + pc] : 0.0;
+        // read-once streams: non-temporal, so they do not evict the {tp, fp} records
+        // (the gather table) from the XCD's L2
+        d.idx[c] = __builtin_nontemporal_load(P.indices + s + pc);
+        d.eta[c] = __builtin_nontemporal_load(P.data + s + pc);
+        d.sel[c] = __builtin_nontemporal_load(P.sel + s + pc);
+        d.sc[c] = P.s_entry ? __builtin_nontemporal_load(P.s_entry + s + pc) : 0.0;
     }
 }
 
@@ -167,7 +173,8 @@ __device__ __forceinline__ unsigned long long wave_umin64(unsigned long long v) 
     return ((unsigned long long)H << 32) | L;
 }
 
-template <typename T, int CH, bool EXACT, bool HAS_ORDER>
+// SHADOW (only with !EXACT, never greedy): gather the float32 copy of the records.
+template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW>
 __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
@@ -179,6 +186,11 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     const int64_t W = P.n_waves;
     const int64_t last = P.n_order - 1;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.tpfp, 0, P.tpfp_bytes, XC_RSRC_WORD3);
+    // float32 shadow of the records: only the concurrent (non-exact), non-greedy sweep reads it
+    // descriptors are built from kernel arguments (scalar registers); a runtime select
+    // between pointers would make hipcc wrap every buffer load in a waterfall loop
+    const __amdgpu_buffer_rsrc_t rsrc32 =
+        __builtin_amdgcn_make_buffer_rsrc(P.shadow, 0, SHADOW ? P.tpfp_bytes / 2 : 0u, XC_RSRC_WORD3);
     unsigned long long n_changed = 0;
 
     // Software pipeline over the wave's positions pos, pos+W, pos+2W, ...:
@@ -199,6 +211,26 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     int s1 = uni(P.indptr[row1]), e1 = uni(P.indptr[row1 + 1]);
     RowData<T, CH> cur;
     load_row<T, CH>(P, s0, e0 - s0, lane, cur);
+    // The from-scratch accumulation of a row's new prediction into `acc` is not
+    // urgent, and vmcnt retires in issue order: issued right after the decision it
+    // would sit in front of the NEXT row's gathers and their wait would pay the
+    // atomics' ~700-cycle round trip.  So a row's acc atomics are issued one
+    // iteration later, just after the next row's gathers.
+    int pend_idx[CH];
+    T pend_eta[CH];
+    bool pend_on[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { pend_idx[c] = 0; pend_eta[c] = (T)0; pend_on[c] = false; }
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (pend_on[c]) {
+                double *a = P.acc + (int64_t)pend_idx[c] * 2;
+                atomic_add_f64(a + 0, (double)pend_eta[c]);
+                atomic_add_f64(a + 1, (double)((T)1 - pend_eta[c]));
+            }
+        }
+    };
 
     XC_STAMP_DECL;
     XC_STAMP_START();
@@ -211,22 +243,30 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // ---- gather the statistics of the candidate labels: one 16-byte
         // {tp, fp} record per candidate, agent-coherent (sc1: served by L2, never by
         // this CU's L1, so other waves' atomics are seen) ----
-        double tp[CH], fp[CH], sc[CH];
+        double2_t rec64[CH];
+        float2_t rec32[CH];
+        double sc[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const uint4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1);
-            const double2_t rec = __builtin_bit_cast(double2_t, raw);
-            tp[c] = rec.x;
-            fp[c] = rec.y;
+            if (SHADOW) {
+                rec32[c] = __builtin_bit_cast(
+                    float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
+            } else {
+                rec64[c] = __builtin_bit_cast(
+                    double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
+            }
             sc[c] = greedy ? load_coherent(P.colsum + cur.idx[c]) : cur.sc[c];
         }
 
         // ---- prefetch for the following rows (issued AFTER the gathers so the
-        // wait on the gathers does not also wait for these) ----
+        // wait on the gathers does not also wait for these; the scheduling barrier
+        // keeps hipcc from hoisting them above the gathers) ----
+        __builtin_amdgcn_sched_barrier(0);
         RowData<T, CH> nxt;
         load_row<T, CH>(P, s1, e1 - s1, lane, nxt);
         const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
         const int row3 = row_at(pos + 3 * W);
+        if (P.acc) flush_pending(); // the previous row's contribution to acc (younger than the gathers)
         XC_STAMP(0); // issue gathers + prefetches
 
         // ---- membership of the candidates in the current prediction comes with
@@ -242,7 +282,10 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         }
         if (P.orphans && !greedy && lane < k) {
             const int oid = P.orphans[row * k + lane];
-            if (oid >= 0) atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
+            if (oid >= 0) {
+                atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
+                if (P.shadow) atomic_add_f32(P.shadow + (int64_t)oid * 2 + 1, -1.0f);
+            }
         }
         XC_STAMP(1); // membership
         // ---- gains (block_coordinate.py:248-282) ----
@@ -255,7 +298,9 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                 const T om = (T)1 - e; // (1 - t_data) in the input dtype, :253
                 const double ed = (double)e;
                 const double omd = (double)om;
-                double tpc = tp[c], fpc = fp[c], scc = sc[c];
+                double tpc = SHADOW ? (double)rec32[c].x : rec64[c].x;
+                double fpc = SHADOW ? (double)rec32[c].y : rec64[c].y;
+                double scc = sc[c];
                 // statistics without this row (:243-246, done in registers)
                 if (in_old[c]) {
                     tpc -= ed;
@@ -395,17 +440,14 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
         const bool row_changed = __ballot(any_change) != 0ull;
         // The from-scratch recompute of the sweep boundary (block_coordinate.py:465-467:
-        // tp / fp of the new prediction summed over ALL rows) is accumulated here, row
-        // by row, instead of by a separate pass over the prediction afterwards.
-        if (P.acc) {
+        // tp / fp of the new prediction summed over ALL rows) is accumulated row by row
+        // instead of by a separate pass over the prediction afterwards; the atomics
+        // themselves go out in the next iteration (flush_pending).
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (in_new[c]) {
-                    double *a = P.acc + (int64_t)cur.idx[c] * 2;
-                    atomic_add_f64(a + 0, (double)cur.eta[c]);
-                    atomic_add_f64(a + 1, (double)((T)1 - cur.eta[c]));
-                }
-            }
+        for (int c = 0; c < CH; ++c) {
+            pend_idx[c] = cur.idx[c];
+            pend_eta[c] = cur.eta[c];
+            pend_on[c] = in_new[c];
         }
         if (row_changed || greedy) {
             int base = 0;
@@ -434,6 +476,11 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                         const double sgn = in_new[c] ? 1.0 : -1.0;
                         atomic_add_f64(st + 0, sgn * ed);
                         atomic_add_f64(st + 1, sgn * omd);
+                        if (P.shadow) { // keep the float32 copy in step
+                            float *sh = P.shadow + (int64_t)cur.idx[c] * 2;
+                            atomic_add_f32(sh + 0, (float)(sgn * ed));
+                            atomic_add_f32(sh + 1, (float)(sgn * omd));
+                        }
                     }
                 }
             }
@@ -457,6 +504,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 #endif
         XC_STAMP(5); // prefetch landing
     }
+    if (P.acc) flush_pending();
 #ifdef XC_STAMPS
     if (P.stamps && lane == 0)
         for (int i = 0; i < XC_NSTAMP; ++i) atomicAdd(P.stamps + i, st_sum[i]);
@@ -524,8 +572,8 @@ __global__ __launch_bounds__(XC_BLOCK) void accumulate_pred_kernel(int64_t n_k, 
 // in-order host sum) do not depend on timing.
 __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, double nn, double n_counted,
                                                                   double *acc, int clear_acc, double *tpfp,
-                                                                  const double *colsum, xc_metric metric,
-                                                                  int skip_tn, double *partials) {
+                                                                  float *shadow, const double *colsum,
+                                                                  xc_metric metric, int skip_tn, double *partials) {
     __shared__ double red[XC_BLOCK];
     const int64_t per = (m + XC_UTILITY_PARTIALS - 1) / XC_UTILITY_PARTIALS;
     const int64_t j0 = (int64_t)blockIdx.x * per;
@@ -538,6 +586,10 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
             fp = acc[2 * j + 1];
             tpfp[2 * j] = tp;
             tpfp[2 * j + 1] = fp;
+            if (shadow) {
+                shadow[2 * j] = (float)tp;
+                shadow[2 * j + 1] = (float)fp;
+            }
             if (clear_acc) {
                 acc[2 * j] = 0.0;
                 acc[2 * j + 1] = 0.0;
@@ -596,29 +648,33 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
 
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
 
-template <typename T, bool EXACT, bool HAS_ORDER>
+template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW>
 static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
     const int blocks = (P.n_waves + 3) / 4;
     switch (ch) {
-    case 1: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 1, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 2: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 2, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 4: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 4, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 8: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 8, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    default: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 16, EXACT, HAS_ORDER>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 1: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 1, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 2: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 2, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 4: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 4, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 8: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 8, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    default: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 16, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
     }
 }
 
 // n_waves == 1 is the sequential mode that must reproduce the reference's
-// trajectory: it keeps the reference's divisions
+// trajectory: it keeps the reference's divisions and reads the float64 records.
+// The float32 shadow is read by the concurrent, non-greedy sweep only.
 template <typename T>
 static void launch_sweep(const SweepParams<T> &P, int ch, hipStream_t st) {
     const bool exact = P.n_waves == 1;
+    const bool shadow = !exact && !P.greedy && P.shadow != nullptr;
     if (P.order) {
-        if (exact) launch_sweep_impl<T, true, true>(P, ch, st);
-        else launch_sweep_impl<T, false, true>(P, ch, st);
+        if (exact) launch_sweep_impl<T, true, true, false>(P, ch, st);
+        else if (shadow) launch_sweep_impl<T, false, true, true>(P, ch, st);
+        else launch_sweep_impl<T, false, true, false>(P, ch, st);
     } else {
-        if (exact) launch_sweep_impl<T, true, false>(P, ch, st);
-        else launch_sweep_impl<T, false, false>(P, ch, st);
+        if (exact) launch_sweep_impl<T, true, false, false>(P, ch, st);
+        else if (shadow) launch_sweep_impl<T, false, false, true>(P, ch, st);
+        else launch_sweep_impl<T, false, false, false>(P, ch, st);
     }
 }
 
@@ -700,14 +756,14 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices, const void 
 }
 
 int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, double *acc, int clear_acc, double *tpfp,
-                          const double *colsum, const xc_metric *metric_host, int skip_tn, double *partials,
-                          void *stream) {
+                          float *shadow, const double *colsum, const xc_metric *metric_host, int skip_tn,
+                          double *partials, void *stream) {
     if (m < 0 || n_norm < 1 || !tpfp || !colsum || !metric_host || !partials)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: bad argument");
     if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: unknown metric %d", metric_host->base);
     hipLaunchKernelGGL(xc::commit_utility_kernel, dim3(XC_UTILITY_PARTIALS), dim3(XC_BLOCK), 0, xc::as_stream(stream), m,
-                       (double)n_norm, n_counted, acc, clear_acc, tpfp, colsum, *metric_host, skip_tn, partials);
+                       (double)n_norm, n_counted, acc, clear_acc, tpfp, shadow, colsum, *metric_host, skip_tn, partials);
     XC_CHECK_LAUNCH("commit_utility_kernel");
     return XC_OK;
 }
@@ -740,7 +796,7 @@ int xc_utility_finish_host(const double *partials, double *out_host, double *out
 int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz,
                      int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     int64_t m, double *tpfp, double *colsum, const double *s_entry, double *acc,
+                     int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, double *acc,
                      const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
                      int64_t *changed, void *stream) {
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
@@ -766,14 +822,14 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
     fast.kf *= (double)n_norm;
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
-                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry, acc, m,
+                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry, acc, m,
                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<float>(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
-                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, colsum, greedy ? nullptr : s_entry, acc, m,
+                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry, acc, m,
                                   (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                   (double)n_norm, maximize, greedy, skip_tn, n_waves,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
