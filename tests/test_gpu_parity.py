@@ -298,3 +298,106 @@ def test_api_contract_and_errors():
             assert type(P) == type(inp) and P.dtype == inp.dtype
             s = P.sum(axis=1) if not isinstance(P, torch.Tensor) else P.sum(dim=1).cpu().numpy()
             assert (np.asarray(s).ravel() == 3).all()
+
+
+# ---------------------------------------------------------------------------
+# harder shapes for the sweep kernel, exact sequential mode vs the oracle
+# ---------------------------------------------------------------------------
+
+def _ragged_csr(n, m, rmin, rmax, seed, dtype=np.float32, quantize=None):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(rmin, rmax + 1, size=n)
+    lens[:5] = [rmin, 64, 65, 129, rmax]
+    cols = np.concatenate([np.sort(rng.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.random(cols.size) ** 2
+    if quantize:
+        data = np.ceil(data * quantize) / quantize      # few distinct values -> many exactly equal gains
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return csr_matrix((np.clip(data, 1e-3, 1.0).astype(dtype), cols, indptr), shape=(n, m))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_bca_csr_long_ragged_rows_exact(oref, dtype):
+    """Rows of 5..700 entries: 1, 2, 4, 8 and 16 candidates per lane, chunked ballots,
+    the swap loop and the bisection fallback across chunks."""
+    from xcolumns_amd.block_coordinate import predict_using_bc_with_0approx
+    from xcolumns_amd.metrics import binary_f1_score_on_conf_matrix, binary_balanced_accuracy_on_conf_matrix
+    n, m, k = 500, 3000, 5
+    Y = _ragged_csr(n, m, k, 700, 31, dtype=dtype)
+    for fn_, base, skip_tn in ((binary_f1_score_on_conf_matrix, oref.FBETA, True),
+                              (binary_balanced_accuracy_on_conf_matrix, oref.BALANCED_ACC, False)):
+        metric = oref.make_metric(base, k=float(k), m=float(m))
+        Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=skip_tn, seed=3, max_iters=3, tolerance=-1.0)
+        Pg, mg = predict_using_bc_with_0approx(Y, fn_, k, skip_tn=skip_tn, seed=3, max_iters=3, tolerance=-1.0,
+                                               return_meta=True, bca_waves=1)
+        assert np.allclose(mg["utilities"], mo["utilities"], rtol=0, atol=1e-12), (mg["utilities"], mo["utilities"])
+        assert np.array_equal(Pg.indices, Po.indices)
+        # concurrent mode on the same input: valid prediction, close utility
+        Pc, mc = predict_using_bc_with_0approx(Y, fn_, k, skip_tn=skip_tn, seed=3, max_iters=3, tolerance=-1.0,
+                                               return_meta=True, bca_waves=8)
+        assert abs(mc["utilities"][-1] - mo["utilities"][-1]) < 1e-4
+        assert (np.diff(Pc.indices.reshape(n, k), axis=1) > 0).all()
+
+
+def test_bca_csr_ties_exact(oref):
+    """Scores quantised to 8 levels: many exactly equal gains at the top-k boundary;
+    the lower column must win, as in the oracle."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_recall_using_bc, predict_optimizing_macro_f1_score_using_bc
+    n, m, k = 600, 40, 3
+    Y = _ragged_csr(n, m, k, 30, 77, quantize=8)
+    for fn_, base in ((predict_optimizing_macro_f1_score_using_bc, oref.FBETA),
+                      (predict_optimizing_macro_recall_using_bc, oref.RECALL)):
+        metric = oref.make_metric(base, k=float(k), m=float(m))
+        Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=5, max_iters=3, tolerance=-1.0)
+        Pg, mg = fn_(Y, k, seed=5, max_iters=3, tolerance=-1.0, return_meta=True, bca_waves=1)
+        assert np.allclose(mg["utilities"], mo["utilities"], rtol=0, atol=1e-12)
+        assert np.array_equal(Pg.indices, Po.indices)
+    # top-k itself with ties
+    from xcolumns_amd.weighted_prediction import predict_top_k
+    assert np.array_equal(predict_top_k(Y, k).indices, oref.predict_top_k(Y, k).indices)
+
+
+def test_bca_csr_not_normalized_quirk(oref):
+    """normalize_conf_matrix=False: the reference then visits ONLY row 0 and divides the
+    utility by 1 (block_coordinate.py:403-405, :414); the step still divides by n."""
+    from xcolumns_amd.block_coordinate import predict_using_bc_with_0approx
+    from xcolumns_amd.metrics import binary_f1_score_on_conf_matrix
+    n, m, k = 300, 50, 3
+    Y = _ragged_csr(n, m, k, 20, 9)
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=1, max_iters=2, tolerance=-1.0,
+                                                normalize_conf_matrix=False)
+    Pg, mg = predict_using_bc_with_0approx(Y, binary_f1_score_on_conf_matrix, k, skip_tn=True, seed=1, max_iters=2,
+                                           tolerance=-1.0, normalize_conf_matrix=False, return_meta=True, bca_waves=1)
+    assert np.allclose(mg["utilities"], mo["utilities"], rtol=0, atol=1e-12)
+    assert np.array_equal(Pg.indices, Po.indices)
+
+
+def test_bca_shadow_on_off_agree():
+    """The float32 shadow of the {tp, fp} records (gathered by the concurrent sweep) and
+    the float64 records themselves lead to the same optimum within the parity bar."""
+    from xcolumns_amd import _device as D, _lib
+    from xcolumns_amd.block_coordinate import BcaCsrEngine, WavePolicy, run_bca_sweeps
+    from xcolumns_amd.metrics import MetricSpec
+    n, m, k = 30000, 5000, 5
+    Y = _synthetic_csr(n, m, 40, 4242)
+    dev = D.require_gpu()
+    csr = D.DeviceCSR.from_scipy(Y, dev)
+    spec = MetricSpec(base=_lib.XC_M_FBETA)
+    finals = []
+    for shadow in (True, False):
+        eng = BcaCsrEngine(csr, k, spec, spec, skip_tn=True, use_shadow=shadow)
+        eng.init_top()
+        rng = np.random.default_rng(13)
+        order = np.arange(n)
+
+        def nxt():
+            rng.shuffle(order)
+            return torch.from_numpy(order.astype(np.int32)).to(dev)
+
+        meta = {"utilities": [], "iters": 0}
+        run_bca_sweeps(eng, nxt, n, n, m, "mean", True, -1.0, 5, False, WavePolicy(n), False, meta)
+        finals.append(meta["utilities"])
+    d = np.abs(np.asarray(finals[0]) - np.asarray(finals[1]))
+    print("shadow on/off utility diff per sweep:", d)
+    assert d[-1] < FINAL_TOL and d.max() < PER_SWEEP_TOL

@@ -115,7 +115,7 @@ class BcaCsrEngine:
 
     def __init__(self, csr: D.DeviceCSR, k: int, gain_spec: MetricSpec, utility_spec: MetricSpec,
                  maximize: bool = True, skip_tn: bool = False, n_total: Optional[int] = None,
-                 comm=None):
+                 comm=None, use_shadow: Optional[bool] = None):
         if k < 1 or k > _lib.XC_MAX_K:
             raise ValueError(f"k must be in 1..{_lib.XC_MAX_K} for sparse y_proba on the GPU, got {k}")
         self.csr = csr
@@ -131,8 +131,9 @@ class BcaCsrEngine:
         m = csr.m
         self.tpfp = torch.zeros((m, 2), dtype=torch.float64, device=dev)
         # float32 copy of tpfp gathered by the concurrent sweep (XCOLUMNS_BCA_SHADOW=0 disables)
-        self.shadow = (torch.zeros((m, 2), dtype=torch.float32, device=dev)
-                       if os.environ.get("XCOLUMNS_BCA_SHADOW", "1") != "0" else None)
+        if use_shadow is None:
+            use_shadow = os.environ.get("XCOLUMNS_BCA_SHADOW", "1") != "0"
+        self.shadow = torch.zeros((m, 2), dtype=torch.float32, device=dev) if use_shadow else None
         self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
         self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
         # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count

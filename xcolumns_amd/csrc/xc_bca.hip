@@ -79,14 +79,6 @@ struct SweepParams {
 #define XC_STAMP(i)
 #endif
 
-// Order-preserving map from float64 to uint64 (larger gain -> larger key).  NaN
-// was mapped to -inf before.  Every finite/infinite double maps to a key >= 1
-// (-inf -> 0x000fffffffffffff), so key 0 marks "no candidate".
-__device__ __forceinline__ unsigned long long sortable_key(double g) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(g);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-
 // Normalisation by n (block_coordinate.py:252-264).  EXACT divides every entry by
 // n like the reference (bit-identical gains; the sequential mode that must
 // reproduce the reference's trajectory).  The concurrent mode skips it: every
@@ -126,51 +118,6 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
         d.sel[c] = __builtin_nontemporal_load(P.sel + s + pc);
         d.sc[c] = P.s_entry ? __builtin_nontemporal_load(P.s_entry + s + pc) : 0.0;
     }
-}
-
-// ---- wavefront reductions on DPP (gfx9 row_shr / row_bcast) -------------------
-// v_max_u32_dpp etc.: one VALU instruction per step, no LDS crossbar.  After the
-// four row_shr steps lane 15 of each 16-lane row holds the row's result;
-// row_bcast:15 / row_bcast:31 carry it across rows so lane 63 holds the wave's.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_src(unsigned identity, unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-
-__device__ __forceinline__ unsigned wave_umax32(unsigned v) {
-    v = max(v, dpp_src<0x111, 0xF>(0u, v)); // row_shr:1
-    v = max(v, dpp_src<0x112, 0xF>(0u, v)); // row_shr:2
-    v = max(v, dpp_src<0x114, 0xF>(0u, v)); // row_shr:4
-    v = max(v, dpp_src<0x118, 0xF>(0u, v)); // row_shr:8
-    v = max(v, dpp_src<0x142, 0xA>(0u, v)); // row_bcast:15 into rows 1, 3
-    v = max(v, dpp_src<0x143, 0xC>(0u, v)); // row_bcast:31 into rows 2, 3
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-__device__ __forceinline__ unsigned wave_umin32(unsigned v) {
-    v = min(v, dpp_src<0x111, 0xF>(~0u, v));
-    v = min(v, dpp_src<0x112, 0xF>(~0u, v));
-    v = min(v, dpp_src<0x114, 0xF>(~0u, v));
-    v = min(v, dpp_src<0x118, 0xF>(~0u, v));
-    v = min(v, dpp_src<0x142, 0xA>(~0u, v));
-    v = min(v, dpp_src<0x143, 0xC>(~0u, v));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// 64-bit max / min as two 32-bit reductions: high words first, then the low words
-// of the lanes that hold the winning high word
-__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {
-    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-    const unsigned H = wave_umax32(hi);
-    const unsigned L = wave_umax32(hi == H ? lo : 0u);
-    return ((unsigned long long)H << 32) | L;
-}
-
-__device__ __forceinline__ unsigned long long wave_umin64(unsigned long long v) {
-    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-    const unsigned H = wave_umin32(hi);
-    const unsigned L = wave_umin32(hi == H ? lo : ~0u);
-    return ((unsigned long long)H << 32) | L;
 }
 
 // SHADOW (only with !EXACT, never greedy): gather the float32 copy of the records.

@@ -73,6 +73,65 @@ __device__ __forceinline__ Best<G> wave_argmax(Best<G> b) {
     return b; // identical in all lanes
 }
 
+// ---- wavefront reductions on DPP (gfx9 row_shr / row_bcast) -------------------
+// v_max_u32_dpp etc.: one VALU instruction per step, no LDS crossbar.  After the
+// four row_shr steps lane 15 of each 16-lane row holds the row's result;
+// row_bcast:15 / row_bcast:31 carry it across rows so lane 63 holds the wave's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_src(unsigned identity, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ unsigned wave_umax32(unsigned v) {
+    v = max(v, dpp_src<0x111, 0xF>(0u, v)); // row_shr:1
+    v = max(v, dpp_src<0x112, 0xF>(0u, v)); // row_shr:2
+    v = max(v, dpp_src<0x114, 0xF>(0u, v)); // row_shr:4
+    v = max(v, dpp_src<0x118, 0xF>(0u, v)); // row_shr:8
+    v = max(v, dpp_src<0x142, 0xA>(0u, v)); // row_bcast:15 into rows 1, 3
+    v = max(v, dpp_src<0x143, 0xC>(0u, v)); // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ unsigned wave_umin32(unsigned v) {
+    v = min(v, dpp_src<0x111, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x112, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x114, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x118, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x142, 0xA>(~0u, v));
+    v = min(v, dpp_src<0x143, 0xC>(~0u, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// 64-bit max / min as two 32-bit reductions: high words first, then the low words
+// of the lanes that hold the winning high word
+__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned H = wave_umax32(hi);
+    const unsigned L = wave_umax32(hi == H ? lo : 0u);
+    return ((unsigned long long)H << 32) | L;
+}
+
+__device__ __forceinline__ unsigned long long wave_umin64(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned H = wave_umin32(hi);
+    const unsigned L = wave_umin32(hi == H ? lo : ~0u);
+    return ((unsigned long long)H << 32) | L;
+}
+
+// Order-preserving map from float64 to uint64 (larger gain -> larger key).  NaN
+// was mapped to -inf before.  Every finite/infinite double maps to a key >= 1
+// (-inf -> 0x000fffffffffffff), so key 0 marks "no candidate".
+__device__ __forceinline__ unsigned long long sortable_key(double g) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(g);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// float32 flavour: every non-NaN float maps to a key >= 1 (0 = no candidate)
+__device__ __forceinline__ unsigned sortable_key32(float g) {
+    const unsigned u = __float_as_uint(g);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+
 // ---- division ------------------------------------------------------------------
 // EXACT: IEEE division, bit-identical to the reference's numpy `/`.
 // Otherwise: v_rcp_f64 refined by two Newton steps, then one multiply -- about

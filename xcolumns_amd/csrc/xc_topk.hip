@@ -33,34 +33,79 @@ struct TopkParams {
     int n_waves;
 };
 
+// sortable key of a gain in its own dtype: uint32 for float32 rows, uint64 for float64
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> {
+    typedef unsigned type;
+    static __device__ __forceinline__ type make(float g) { return sortable_key32(nan_to_neg_inf(g)); }
+    static __device__ __forceinline__ type wave_max(type v) { return wave_umax32(v); }
+};
+template <> struct KeyOf<double> {
+    typedef unsigned long long type;
+    static __device__ __forceinline__ type make(double g) { return sortable_key(nan_to_neg_inf(g)); }
+    static __device__ __forceinline__ type wave_max(type v) { return wave_umax64(v); }
+};
+
+template <typename T, int CH>
+struct TopkRow {
+    int idx[CH];
+    T eta[CH];
+};
+
+template <typename T, int CH>
+__device__ __forceinline__ void topk_load_row(const TopkParams<T> &P, int s, int r, int lane, TopkRow<T, CH> &d) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int p = lane + XC_WAVE * c;
+        const int pc = p < r ? p : (r > 0 ? r - 1 : 0);
+        // read-once streams (clamped, all lanes: straight-line loads)
+        d.idx[c] = r > 0 ? __builtin_nontemporal_load(P.indices + s + pc) : 0;
+        d.eta[c] = r > 0 ? __builtin_nontemporal_load(P.data + s + pc) : (T)0;
+    }
+}
+
 template <typename T, int CH>
 __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
+    typedef typename KeyOf<T>::type key_t;
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
     if (wave >= P.n_waves) return;
     const int k = P.k;
+    const int64_t W = P.n_waves;
+    const int64_t last = P.n - 1;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto clampr = [&](int64_t r) { return r < last ? r : last; };
 
-    for (int64_t row = wave; row < P.n; row += P.n_waves) {
-        const int s = P.indptr[row];
-        const int r = P.indptr[row + 1] - s;
+    // software pipeline: the entries of row t+1 and the indptr pair of row t+2 are
+    // in flight while row t is selected
+    int64_t row = wave;
+    int s0 = uni(P.indptr[row]), e0 = uni(P.indptr[row + 1]);
+    int s1 = uni(P.indptr[clampr(row + W)]), e1 = uni(P.indptr[clampr(row + W) + 1]);
+    TopkRow<T, CH> cur;
+    topk_load_row<T, CH>(P, s0, e0 - s0, lane, cur);
+
+    for (; row < P.n; row += W) {
+        const int s = s0, r = e0 - s0;
+        TopkRow<T, CH> nxt;
+        topk_load_row<T, CH>(P, s1, e1 - s1, lane, nxt);
+        const int64_t row2 = clampr(row + 2 * W);
+        const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
+
         int32_t *o_idx = P.out_indices + row * k;
         T *o_dat = P.out_data + row * k;
         T *o_eta = P.out_eta ? P.out_eta + row * k : nullptr;
 
-        int idx[CH];
-        T eta[CH];
         T gain[CH];
+        key_t key[CH];
         bool sel[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int p = lane + XC_WAVE * c;
-            const bool valid = p < r;
-            idx[c] = valid ? P.indices[s + p] : -1;
-            eta[c] = valid ? P.data[s + p] : (T)0;
-            T g = eta[c];
-            if (valid && P.a) g = g * P.a[idx[c]]; // numba_csr_functions.py:608-609
-            if (valid && P.b) g = g + P.b[idx[c]]; // :610-611
+            const bool valid = lane + XC_WAVE * c < r;
+            T g = cur.eta[c];
+            if (P.a) g = g * P.a[cur.idx[c]]; // numba_csr_functions.py:608-609
+            if (P.b) g = g + P.b[cur.idx[c]]; // :610-611
             gain[c] = g;
+            key[c] = valid ? KeyOf<T>::make(g) : (key_t)0;
             sel[c] = false;
         }
 
@@ -71,23 +116,23 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
             for (int c = 0; c < CH; ++c) sel[c] = (lane + XC_WAVE * c) < r;
             n_sel = r;
         } else {
+            // k rounds: wave max of the remaining keys (DPP), winner = its first
+            // holder in position order (ties go to the lower column)
             for (int round = 0; round < k; ++round) {
-                Best<T> b{(T)-INFINITY, INT_MAX};
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int p = lane + XC_WAVE * c;
-                    if (p < r && !sel[c]) {
-                        const T key = nan_to_neg_inf(gain[c]);
-                        if (beats(key, p, b.g, b.p)) {
-                            b.g = key;
-                            b.p = p;
-                        }
-                    }
-                }
-                b = wave_argmax(b);
+                key_t lmax = 0;
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
-                    if (lane + XC_WAVE * c == b.p) sel[c] = true;
+                    if (!sel[c] && key[c] > lmax) lmax = key[c];
+                const key_t M = KeyOf<T>::wave_max(lmax);
+                bool found = false;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const unsigned long long mask = __ballot(!sel[c] && key[c] == M);
+                    if (!found && mask != 0ull) {
+                        if (lane == __ffsll((long long)mask) - 1) sel[c] = true;
+                        found = true;
+                    }
+                }
             }
             n_sel = k;
         }
@@ -99,9 +144,9 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
             const unsigned long long mask = __ballot(sel[c]);
             if (sel[c]) {
                 const int slot = base + __popcll(mask & lanemask_lt());
-                o_idx[slot] = idx[c];
+                o_idx[slot] = cur.idx[c];
                 o_dat[slot] = P.keep_scores ? gain[c] : (T)1;
-                if (o_eta) o_eta[slot] = eta[c];
+                if (o_eta) o_eta[slot] = cur.eta[c];
             }
             base += __popcll(mask);
             if (P.out_sel && lane + XC_WAVE * c < r) P.out_sel[s + lane + XC_WAVE * c] = sel[c] ? 1 : 0;
@@ -112,6 +157,10 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
             o_dat[lane] = (T)1;
             if (o_eta) o_eta[lane] = (T)0;
         }
+
+        cur = nxt;
+        s0 = s1; e0 = e1;
+        s1 = uni(s2); e1 = uni(e2);
     }
 }
 
