@@ -307,7 +307,7 @@ def test_api_contract_and_errors():
 def _ragged_csr(n, m, rmin, rmax, seed, dtype=np.float32, quantize=None):
     rng = np.random.default_rng(seed)
     lens = rng.integers(rmin, rmax + 1, size=n)
-    lens[:5] = [rmin, 64, 65, 129, rmax]
+    lens[:5] = np.minimum([rmin, 64, 65, 129, rmax], rmax)
     cols = np.concatenate([np.sort(rng.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
     data = rng.random(cols.size) ** 2
     if quantize:
