@@ -240,6 +240,11 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      const double *s_entry, double *acc, const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
+/* Concurrent sweeps re-read, before committing a changed row, the records of the
+ * labels it adds or drops and re-score the row if another wavefront moved them
+ * (optimistic validation; default on).  Process-wide switch, mainly for studies. */
+int xc_bca_set_validation(int on);
+
 /* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */
 int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum,

@@ -70,6 +70,7 @@ SIGNATURES = {
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, POINTER(XcMetric),
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xc_bca_set_validation": (c_int, [c_int]),
     "xc_bca_state_unpack": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     "xc_bca_sweep_dense": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,

@@ -61,6 +61,7 @@ struct SweepParams {
     int greedy;
     int skip_tn;
     int n_waves;
+    int validate; // concurrent mode: re-read the records of the labels a row is about to change
     unsigned long long *changed;
     unsigned long long *stamps; // diagnostic builds only (-DXC_STAMPS): per-phase cycle sums
 };
@@ -93,6 +94,7 @@ typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 #define XC_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
 #define XC_CPOL_SC1 16           /* cache policy bit 4 = sc1 on gfx94x/gfx950 */
+#define XC_MAX_RETRY 3           /* optimistic validation: re-score a row at most this often */
 
 template <typename T, int CH>
 struct RowData {
@@ -235,6 +237,16 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             }
         }
         XC_STAMP(1); // membership
+        // Optimistic validation (concurrent mode): a row that decides to CHANGE its
+        // prediction re-reads the records of all its candidates; if a record of a
+        // label it is about to add or drop moved meanwhile (another wave changed the
+        // same label), the row is re-scored on the fresh records.  Two rows in
+        // flight that both want the same label are thereby serialised like in the
+        // sequential sweep; rows that change nothing pay nothing.
+        bool in_new[CH];
+        bool row_changed = false;
+        const int kk = r < k ? r : k;
+        for (int attempt = 0;; ++attempt) {
         // ---- gains (block_coordinate.py:248-282) ----
         unsigned long long key[CH];
 #pragma unroll
@@ -299,8 +311,6 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // Two DPP wave reductions per check.  Any tie at the boundary, or a
         // prediction that does not hold exactly k of the row's entries, goes to
         // the exact path below.
-        const int kk = r < k ? r : k;
-        bool in_new[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) in_new[c] = in_old[c];
         bool exact_path = (n_old != kk);
@@ -381,11 +391,29 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 
         // ---- write the new prediction (ascending columns) and push the change
         // of the statistics (:290-293 minus :243-246) to memory ----
-        XC_STAMP(3); // top-k
         bool any_change = false;
 #pragma unroll
         for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
-        const bool row_changed = __ballot(any_change) != 0ull;
+        row_changed = __ballot(any_change) != 0ull;
+        if (EXACT || greedy || !P.validate || !row_changed || attempt >= XC_MAX_RETRY) break;
+        bool moved = false;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (SHADOW) {
+                const float2_t now = __builtin_bit_cast(
+                    float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
+                moved = moved || ((in_new[c] != in_old[c]) && (now.x != rec32[c].x || now.y != rec32[c].y));
+                rec32[c] = now;
+            } else {
+                const double2_t now = __builtin_bit_cast(
+                    double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
+                moved = moved || ((in_new[c] != in_old[c]) && (now.x != rec64[c].x || now.y != rec64[c].y));
+                rec64[c] = now;
+            }
+        }
+        if (__ballot(moved) == 0ull) break;
+        } // retry
+        XC_STAMP(3); // top-k
         // The from-scratch recompute of the sweep boundary (block_coordinate.py:465-467:
         // tp / fp of the new prediction summed over ALL rows) is accumulated row by row
         // instead of by a separate pass over the prediction afterwards; the atomics
@@ -594,6 +622,7 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
 }
 
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
+static int g_validate = 1;                           // xc_bca_set_validation
 
 template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW>
 static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
@@ -771,18 +800,23 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
                                  static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry, acc, m,
                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
-                                 (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                 (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<float>(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
                                   static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry, acc, m,
                                   (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
-                                  (double)n_norm, maximize, greedy, skip_tn, n_waves,
+                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
         xc::launch_sweep<double>(P, ch, st);
     }
     XC_CHECK_LAUNCH("bca_sweep_csr_kernel");
+    return XC_OK;
+}
+
+int xc_bca_set_validation(int on) {
+    xc::g_validate = on ? 1 : 0;
     return XC_OK;
 }
 
