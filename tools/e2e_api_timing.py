@@ -30,3 +30,27 @@ for backend in ("numpy", "device"):
 t0 = time.perf_counter()
 T = predict_top_k(Y, 5)
 print(f"{wl} predict_top_k end-to-end: {(time.perf_counter() - t0) * 1e3:.1f} ms -> {n / (time.perf_counter() - t0) / 1e6:.1f} M rows/s")
+
+# BASELINE.json configs[0] shape: dense 3865 x 3956 float32 (EURLex-4K-like), k=5
+from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as _bc  # noqa: E402
+rng = np.random.default_rng(1)
+Yd = (1.0 / (1.0 + np.exp(-rng.normal(-2.0, 1.5, size=(3865, 3956))))).astype(np.float32)
+predict_top_k(Yd[:64], 5)
+for it in range(2):
+    t0 = time.perf_counter()
+    Pd = predict_top_k(Yd, 5)
+    dt = time.perf_counter() - t0
+print(f"C1 dense 3865x3956 f32 predict_top_k (host in/out): {dt * 1e3:.2f} ms -> {3865 / dt / 1e3:.1f} K rows/s")
+Yg = torch.from_numpy(Yd).cuda()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+Pg = predict_top_k(Yg, 5)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"C1 dense predict_top_k (torch GPU tensor in/out): {dt * 1e3:.3f} ms -> {3865 / dt / 1e6:.2f} M rows/s")
+t0 = time.perf_counter()
+Pb, mb = _bc(Yg, 5, seed=0, max_iters=3, tolerance=-1e9, return_meta=True)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"C1 dense BCA macro-F1, 3 sweeps (torch GPU tensor): {dt * 1e3:.1f} ms -> {3865 * 3 / dt / 1e3:.1f} K rows/s, "
+      f"utilities {mb['utilities']}")

@@ -758,9 +758,12 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats, const xc_
 
 int xc_utility_finish_host(const double *partials, double *out_host, double *out_extra_host, void *stream) {
     if (!partials || !out_host) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_utility_finish_host: NULL pointer");
-    double buf[XC_UTILITY_PARTIALS + 1];
+    // pinned staging buffer, allocated once per host thread: a D2H into pageable
+    // memory goes through the runtime's own staging copy and costs several us more
+    static thread_local double *buf = nullptr;
+    if (!buf) XC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&buf), sizeof(double) * (XC_UTILITY_PARTIALS + 1), hipHostMallocDefault));
     hipStream_t st = xc::as_stream(stream);
-    XC_HIP_TRY(hipMemcpyAsync(buf, partials, sizeof(buf), hipMemcpyDeviceToHost, st));
+    XC_HIP_TRY(hipMemcpyAsync(buf, partials, sizeof(double) * (XC_UTILITY_PARTIALS + 1), hipMemcpyDeviceToHost, st));
     XC_HIP_TRY(hipStreamSynchronize(st));
     double sum = 0.0;
     for (int i = 0; i < XC_UTILITY_PARTIALS; ++i) sum += buf[i];
