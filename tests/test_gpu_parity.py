@@ -401,3 +401,66 @@ def test_bca_shadow_on_off_agree():
     d = np.abs(np.asarray(finals[0]) - np.asarray(finals[1]))
     print("shadow on/off utility diff per sweep:", d)
     assert d[-1] < FINAL_TOL and d.max() < PER_SWEEP_TOL
+
+
+# ---------------------------------------------------------------------------
+# the concurrent (non-exact) arithmetic for EVERY metric: psi(x / n; eps, k) is
+# evaluated as psi(x; eps * n, k * n) with reciprocal-based divisions
+# ---------------------------------------------------------------------------
+
+CONCURRENT_METRIC_CASES = [
+    # (xcolumns_amd wrapper or generic metric name, oracle base, skip_tn, aggregation, mixed, metric_kwargs)
+    ("binary_precision_on_conf_matrix", "PRECISION", True, "mean", False, {"epsilon": 0.05}),
+    ("binary_recall_on_conf_matrix", "RECALL", True, "mean", False, {"epsilon": 0.05}),
+    ("binary_fbeta_score_on_conf_matrix", "FBETA", True, "mean", False, {"beta": 2.0, "epsilon": 0.05}),
+    ("binary_jaccard_score_on_conf_matrix", "JACCARD", True, "mean", False, {"epsilon": 0.05}),
+    ("binary_balanced_accuracy_on_conf_matrix", "BALANCED_ACC", False, "mean", False, {"epsilon": 0.05}),
+    ("binary_gmean_on_conf_matrix", "GMEAN", False, "mean", False, {"epsilon": 0.05}),
+    ("binary_hmean_on_conf_matrix", "HMEAN", False, "mean", False, {"epsilon": 0.05}),
+    ("binary_accuracy_on_conf_matrix", "ACCURACY", False, "mean", False, {}),
+]
+
+
+@pytest.mark.parametrize("case", CONCURRENT_METRIC_CASES, ids=[c[1] for c in CONCURRENT_METRIC_CASES])
+def test_bca_concurrent_arithmetic_all_metrics(oref, case):
+    """A large epsilon makes the eps * n rescaling of the concurrent path visible: a
+    wrong scaling would move the optimum by far more than the tolerance."""
+    import xcolumns_amd.metrics as pm
+    from xcolumns_amd.block_coordinate import predict_using_bc_with_0approx
+    name, base, skip_tn, agg, mixed, mk = case
+    n, m, k = 8000, 400, 4
+    Y = _synthetic_csr(n, m, 25, 555)
+    metric = oref.make_metric(getattr(oref, base), epsilon=mk.get("epsilon", 1e-9), beta=mk.get("beta", 1.0),
+                              k=float(k), m=float(m))
+    umetric = oref.make_metric(getattr(oref, base), k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, metric_aggregation=agg, skip_tn=skip_tn, seed=21,
+                                                max_iters=5, tolerance=-1.0, utility_metric=umetric)
+    Pg, mg = predict_using_bc_with_0approx(Y, getattr(pm, name), k, metric_aggregation=agg, skip_tn=skip_tn, seed=21,
+                                           max_iters=5, tolerance=-1.0, metric_kwargs=mk or None, return_meta=True,
+                                           bca_waves=8)
+    d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print(base, "concurrent(8 waves) vs sequential:", d)
+    assert d[-1] < 2e-5 and d.max() < 2e-4, (mg["utilities"], mo["utilities"])
+    same = (Pg.indices.reshape(n, k) == Po.indices.reshape(n, k)).all(axis=1).mean()
+    assert same > 0.97, same
+
+
+@pytest.mark.parametrize("entry", ["predict_optimizing_instance_precision_using_bc",
+                                   "predict_optimizing_mixed_instance_precision_and_macro_f1_score_using_bc",
+                                   "predict_optimizing_mixed_instance_precision_and_macro_hmean_using_bc"])
+def test_bca_concurrent_arithmetic_kf_scaling(oref, entry):
+    """precision@k and the mixed utilities carry the k * n rescaling."""
+    import xcolumns_amd.block_coordinate as bc
+    n, m, k = 8000, 400, 4
+    Y = _synthetic_csr(n, m, 25, 556)
+    spec = {"entry": entry, "k": k, "kwargs": dict(seed=22, max_iters=4, tolerance=-1.0, init_y_pred="top")}
+    if "mixed" in entry:
+        spec["kwargs"]["alpha"] = 0.6
+    Po, mo = G.oracle_call_from_spec(oref, spec, Y)
+    Pg, mg = getattr(bc, entry)(Y, k, return_meta=True, bca_waves=8, **spec["kwargs"])
+    d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    scale = max(1.0, abs(mo["utilities"][-1]))
+    print(entry, d, mo["utilities"])
+    assert d[-1] < 2e-5 * scale and d.max() < 2e-4 * scale
+    same = (Pg.indices.reshape(n, k) == Po.indices.reshape(n, k)).all(axis=1).mean()
+    assert same > 0.97, same
