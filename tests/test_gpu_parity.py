@@ -464,3 +464,38 @@ def test_bca_concurrent_arithmetic_kf_scaling(oref, entry):
     assert d[-1] < 2e-5 * scale and d.max() < 2e-4 * scale
     same = (Pg.indices.reshape(n, k) == Po.indices.reshape(n, k)).all(axis=1).mean()
     assert same > 0.97, same
+
+
+def test_bca_csr_north_star_size_properties():
+    """BASELINE.json's north-star shape (n=1M, m=500K, 50 entries/row, k=5): too large for
+    the oracle in a test, so size-independent properties: valid prediction, the
+    reported utility equals macro-F1 recomputed by the independent confusion kernel,
+    BCA improves on top-k and does not get worse sweep over sweep."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    from xcolumns_amd.confusion_matrix import calculate_confusion_matrix
+    from xcolumns_amd.metrics import binary_f1_score_on_conf_matrix
+    from xcolumns_amd.weighted_prediction import predict_top_k
+    n, m, r, k = 1_000_000, 500_000, 50, 5
+    Y = _synthetic_csr(n, m, r, 20240009)
+    P, meta = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=13, max_iters=4, tolerance=-1.0, return_meta=True)
+    ids = P.indices.reshape(n, k)
+    assert (np.diff(ids, axis=1) > 0).all()
+    sup = Y.indices.reshape(n, r)
+    for i in range(0, n, 49999):                       # predicted labels are stored in their rows
+        assert np.isin(ids[i], sup[i]).all()
+    C = calculate_confusion_matrix(Y, P, normalize=True, skip_tn=True, dtype=np.float64)
+    f1 = binary_f1_score_on_conf_matrix(C.tp, C.fp, C.fn, C.tn).mean()
+    assert abs(f1 - meta["utilities"][-1]) < 1e-10
+    T = predict_top_k(Y, k)
+    Ct = calculate_confusion_matrix(Y, T, normalize=True, skip_tn=True, dtype=np.float64)
+    f1_top = binary_f1_score_on_conf_matrix(Ct.tp, Ct.fp, Ct.fn, Ct.tn).mean()
+    u = np.asarray(meta["utilities"])
+    assert u[0] > f1_top and (np.diff(u) > -1e-6).all(), (f1_top, u)
+    # top-k property at full size: every chosen score >= every unchosen score of its row
+    chosen = np.zeros((n, r), dtype=bool)
+    tid = T.indices.reshape(n, k)
+    for q in range(k):
+        chosen |= sup == tid[:, q:q + 1]
+    assert (chosen.sum(axis=1) == k).all()
+    data = Y.data.reshape(n, r)
+    assert (np.where(chosen, data, np.inf).min(axis=1) >= np.where(~chosen, data, -np.inf).max(axis=1)).all()

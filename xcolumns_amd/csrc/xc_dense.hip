@@ -36,13 +36,43 @@ __device__ __forceinline__ Best<G> block_argmax(Best<G> b, Best<G> *lds /* BLOCK
 }
 
 // ---- dense top-k --------------------------------------------------------------
-// gains: G (promoted dtype), y_pred: P (y_proba's dtype).  Round t picks the best
-// element that is strictly worse than round t-1's winner in the total order
-// (gain desc, column asc), so no selected-set bookkeeping is needed.
+// Workgroup-wide max of a uint64 (DPP wave max, then 4 values through LDS).
+template <int BLOCK>
+__device__ __forceinline__ unsigned long long block_umax64(unsigned long long v, unsigned long long *lds) {
+    v = wave_umax64(v);
+    if (lane_id() == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = 0ull;
+#pragma unroll
+    for (int w = 0; w < BLOCK / XC_WAVE; ++w) r = lds[w] > r ? lds[w] : r;
+    __syncthreads();
+    return r;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ unsigned block_umin32(unsigned v, unsigned *lds) {
+    v = wave_umin32(v);
+    if (lane_id() == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned r = ~0u;
+#pragma unroll
+    for (int w = 0; w < BLOCK / XC_WAVE; ++w) r = lds[w] < r ? lds[w] : r;
+    __syncthreads();
+    return r;
+}
+
+// gains: G (promoted dtype), y_pred: P (y_proba's dtype).  One workgroup per row;
+// the row (<= a few tens of KB) is streamed once from HBM and re-read from L1/L2 in
+// the k selection rounds.  Round t picks the best element strictly worse than round
+// t-1's winner in the total order (gain desc, column asc): no selected-set
+// bookkeeping.  float32 gains use ONE 64-bit key (sortable gain << 32 | ~column), so
+// a round is a single block-wide max; float64 gains take a max round on the sortable
+// gain and a min round on the column among its holders.
 template <typename G, typename P>
 __global__ __launch_bounds__(XC_BLOCK) void topk_dense_kernel(int64_t m, int64_t ld, const G *gains, int k, G th,
                                                               int keep_scores, P *y_pred) {
-    __shared__ Best<G> red[XC_BLOCK / XC_WAVE + 1];
+    __shared__ unsigned long long red64[XC_BLOCK / XC_WAVE];
+    __shared__ unsigned red32[XC_BLOCK / XC_WAVE];
     const int64_t row = blockIdx.x;
     const G *g = gains + row * ld;
     P *o = y_pred + row * m;
@@ -51,21 +81,46 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_dense_kernel(int64_t m, int64_t
         return;
     }
     for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) o[j] = (P)0; // :35
-    Best<G> prev{(G)INFINITY, -1};
     const int rounds = (int64_t)k < m ? k : (int)m;
-    for (int round = 0; round < rounds; ++round) {
-        Best<G> b{(G)-INFINITY, INT_MAX};
-        for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) {
-            const G key = nan_to_neg_inf(g[j]);
-            const int p = (int)j;
-            if (beats(prev.g, prev.p, key, p) && beats(key, p, b.g, b.p)) {
-                b.g = key;
-                b.p = p;
+    if (sizeof(G) == 4) {
+        unsigned long long prev = ~0ull;
+        for (int round = 0; round < rounds; ++round) {
+            unsigned long long best = 0ull;
+            for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) {
+                const unsigned long long key =
+                    ((unsigned long long)sortable_key32(nan_to_neg_inf((float)g[j])) << 32) | (unsigned)(~(unsigned)j);
+                if (key < prev && key > best) best = key;
             }
+            best = block_umax64<XC_BLOCK>(best, red64);
+            const unsigned col = ~(unsigned)best;
+            if (threadIdx.x == 0) o[col] = keep_scores ? (P)g[col] : (P)1; // :47-49
+            prev = best;
         }
-        b = block_argmax<G, XC_BLOCK>(b, red);
-        if (threadIdx.x == 0) o[b.p] = keep_scores ? (P)g[b.p] : (P)1; // :47-49
-        prev = b;
+    } else {
+        unsigned long long prev_key = ~0ull;
+        unsigned prev_col = 0u;
+        bool first = true;
+        for (int round = 0; round < rounds; ++round) {
+            // remaining = strictly after (prev_key, prev_col) in (key desc, col asc)
+            unsigned long long best = 0ull;
+            for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) {
+                const unsigned long long key = sortable_key(nan_to_neg_inf((double)g[j]));
+                const bool rem = first || key < prev_key || (key == prev_key && (unsigned)j > prev_col);
+                if (rem && key > best) best = key;
+            }
+            best = block_umax64<XC_BLOCK>(best, red64);
+            unsigned col = ~0u;
+            for (int64_t j = threadIdx.x; j < m; j += XC_BLOCK) {
+                const unsigned long long key = sortable_key(nan_to_neg_inf((double)g[j]));
+                const bool rem = first || key < prev_key || (key == prev_key && (unsigned)j > prev_col);
+                if (rem && key == best && (unsigned)j < col) col = (unsigned)j;
+            }
+            col = block_umin32<XC_BLOCK>(col, red32);
+            if (threadIdx.x == 0) o[col] = keep_scores ? (P)g[col] : (P)1;
+            prev_key = best;
+            prev_col = col;
+            first = false;
+        }
     }
 }
 
