@@ -11,54 +11,47 @@ import numpy as np
 import torch
 from scipy.sparse import csr_matrix
 
+# same logger name and level as the reference, so existing logging configuration applies
 logging.basicConfig()
-logger = logging.getLogger("xcolumns")  # same logger name as the reference (utils.py:21-23)
+logger = logging.getLogger("xcolumns")
 logger.setLevel(logging.INFO)
 
 
 def log(msg: str, verbose: bool = True, level: int = logging.INFO):
+    """Emit `msg` on the package logger when `verbose` (the `verbose=` flag of the API)."""
     if verbose:
         logger.log(level, msg)
 
 
-def log_info(msg: str, verbose: bool = True):
-    log(msg, verbose, level=logging.INFO)
+def _leveled(level: int):
+    def emit(msg: str, verbose: bool = True):
+        log(msg, verbose, level=level)
+    return emit
 
 
-def log_debug(msg: str, verbose: bool = True):
-    log(msg, verbose, level=logging.DEBUG)
+log_debug = _leveled(logging.DEBUG)
+log_info = _leveled(logging.INFO)
+log_warning = _leveled(logging.WARNING)
+log_error = _leveled(logging.ERROR)
 
 
-def log_warning(msg: str, verbose: bool = True):
-    log(msg, verbose, level=logging.WARNING)
-
-
-def log_error(msg: str, verbose: bool = True):
-    log(msg, verbose, level=logging.ERROR)
+def _filled_like(a, fill: float, shape, dtype):
+    """A dense array of `fill` living where `a` lives: numpy for ndarray / csr_matrix
+    inputs, a tensor on `a`'s device for torch inputs; shape / dtype default to a's."""
+    shape = a.shape if shape is None else shape
+    if isinstance(a, torch.Tensor):
+        return torch.full(shape, fill, dtype=a.dtype if dtype is None else dtype, device=a.device)
+    if isinstance(a, (np.ndarray, csr_matrix)):
+        return np.full(shape, fill, dtype=a.dtype if dtype is None else dtype)
+    raise ValueError(f"Unsupported type {type(a)}")
 
 
 def zeros_like(a, shape: Tuple[int, ...] = None, dtype=None):
-    """utils.py:52-69."""
-    if isinstance(a, np.ndarray):
-        return np.zeros_like(a, shape=shape, dtype=dtype)
-    if isinstance(a, csr_matrix):
-        return np.zeros(shape if shape is not None else a.shape, dtype=dtype if dtype is not None else a.dtype)
-    if isinstance(a, torch.Tensor):
-        return torch.zeros(shape if shape is not None else a.shape,
-                           dtype=dtype if dtype is not None else a.dtype, device=a.device)
-    raise ValueError(f"Unsupported type {type(a)}")
+    return _filled_like(a, 0, shape, dtype)
 
 
 def ones_like(a, shape: Tuple[int, ...] = None, dtype=None):
-    """utils.py:72-89."""
-    if isinstance(a, np.ndarray):
-        return np.ones_like(a, shape=shape, dtype=dtype)
-    if isinstance(a, csr_matrix):
-        return np.ones(shape if shape is not None else a.shape, dtype=dtype if dtype is not None else a.dtype)
-    if isinstance(a, torch.Tensor):
-        return torch.ones(shape if shape is not None else a.shape,
-                          dtype=dtype if dtype is not None else a.dtype, device=a.device)
-    raise ValueError(f"Unsupported type {type(a)}")
+    return _filled_like(a, 1, shape, dtype)
 
 
 def random_at_k_np(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[int] = None) -> np.ndarray:
