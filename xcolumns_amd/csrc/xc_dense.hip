@@ -16,25 +16,6 @@
 
 namespace xc {
 
-// Workgroup-wide arg-best over (key, position); every thread returns the winner.
-// `smaller_first` orders by ascending key (used on negated gains), else descending.
-template <typename G, int BLOCK>
-__device__ __forceinline__ Best<G> block_argmax(Best<G> b, Best<G> *lds /* BLOCK/64 + 1 */) {
-    b = wave_argmax(b);
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) lds[w] = b;
-    __syncthreads();
-    if (threadIdx.x < XC_WAVE) {
-        Best<G> v = (threadIdx.x < BLOCK / XC_WAVE) ? lds[threadIdx.x] : Best<G>{(G)-INFINITY, INT_MAX};
-        v = wave_argmax(v);
-        if (threadIdx.x == 0) lds[BLOCK / XC_WAVE] = v;
-    }
-    __syncthreads();
-    Best<G> r = lds[BLOCK / XC_WAVE];
-    __syncthreads();
-    return r;
-}
-
 // ---- dense top-k --------------------------------------------------------------
 // Workgroup-wide max of a uint64 (DPP wave max, then 4 values through LDS).
 template <int BLOCK>
@@ -143,9 +124,13 @@ struct DenseSweepParams {
     int maximize, greedy, skip_tn;
 };
 
-template <typename T>
+// EPT > 0: every thread keeps the sortable keys of its <= EPT labels in registers
+// for the k selection rounds (m <= EPT * 1024); EPT == 0: they are re-read from the
+// gains workspace each round (any m up to 65536).
+template <typename T, int EPT>
 __global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_kernel(DenseSweepParams<T> P) {
-    __shared__ Best<double> red[XC_DENSE_BLOCK / XC_WAVE + 1];
+    __shared__ unsigned long long red64[XC_DENSE_BLOCK / XC_WAVE];
+    __shared__ unsigned red32[XC_DENSE_BLOCK / XC_WAVE];
     const int64_t m = P.m;
     const double nn = P.nn;
     const T one = (T)1;
@@ -179,24 +164,59 @@ __global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_kernel(DenseSw
             pred[j] = (T)0; // :191
         }
         __syncthreads();
+        unsigned long long keys[EPT > 0 ? EPT : 1];
+        if (EPT > 0) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+                keys[e] = j < m ? sortable_key(nan_to_neg_inf(P.gains[j])) : 0ull;
+            }
+        }
 
         unsigned long long mine = 0ull; // selected labels among this thread's (bit e <-> j = tid + e * BLOCK)
         if (P.k > 0) {
-            Best<double> prev{INFINITY, -1};
+            // k rounds; each: block max of the sortable gain among the labels strictly
+            // after the previous winner in (gain desc, column asc), then block min of
+            // the column among its holders -- DPP wave reductions, 16 values via LDS
+            unsigned long long prev_key = ~0ull;
+            unsigned prev_col = 0u;
+            bool first = true;
             const int rounds = (int64_t)P.k < m ? P.k : (int)m;
             for (int round = 0; round < rounds; ++round) {
-                Best<double> b{-INFINITY, INT_MAX};
-                for (int64_t j = threadIdx.x; j < m; j += XC_DENSE_BLOCK) {
-                    const double key = nan_to_neg_inf(P.gains[j]);
-                    const int p = (int)j;
-                    if (beats(prev.g, prev.p, key, p) && beats(key, p, b.g, b.p)) {
-                        b.g = key;
-                        b.p = p;
+                unsigned long long best = 0ull;
+                unsigned col = ~0u;
+                if (EPT > 0) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) {
+                        const unsigned j = threadIdx.x + e * XC_DENSE_BLOCK;
+                        const bool rem = first || keys[e] < prev_key || (keys[e] == prev_key && j > prev_col);
+                        if (rem && keys[e] > best) best = keys[e]; // key 0 = past the row's end
+                    }
+                    best = block_umax64<XC_DENSE_BLOCK>(best, red64);
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) {
+                        const unsigned j = threadIdx.x + e * XC_DENSE_BLOCK;
+                        const bool rem = first || keys[e] < prev_key || (keys[e] == prev_key && j > prev_col);
+                        if (rem && keys[e] == best && j < col) col = j;
+                    }
+                } else {
+                    for (int64_t j = threadIdx.x; j < m; j += XC_DENSE_BLOCK) {
+                        const unsigned long long key = sortable_key(nan_to_neg_inf(P.gains[j]));
+                        const bool rem = first || key < prev_key || (key == prev_key && (unsigned)j > prev_col);
+                        if (rem && key > best) best = key;
+                    }
+                    best = block_umax64<XC_DENSE_BLOCK>(best, red64);
+                    for (int64_t j = threadIdx.x; j < m; j += XC_DENSE_BLOCK) {
+                        const unsigned long long key = sortable_key(nan_to_neg_inf(P.gains[j]));
+                        const bool rem = first || key < prev_key || (key == prev_key && (unsigned)j > prev_col);
+                        if (rem && key == best && (unsigned)j < col) col = (unsigned)j;
                     }
                 }
-                b = block_argmax<double, XC_DENSE_BLOCK>(b, red);
-                if ((b.p % XC_DENSE_BLOCK) == (int)threadIdx.x) mine |= 1ull << (b.p / XC_DENSE_BLOCK);
-                prev = b;
+                col = block_umin32<XC_DENSE_BLOCK>(col, red32);
+                if ((col % XC_DENSE_BLOCK) == threadIdx.x) mine |= 1ull << (col / XC_DENSE_BLOCK);
+                prev_key = best;
+                prev_col = col;
+                first = false;
             }
         }
 
@@ -216,6 +236,143 @@ __global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_kernel(DenseSw
             if (!P.skip_tn) P.tn[j] += (double)(T)((one - p) * om);
         }
         __syncthreads();
+    }
+}
+
+// Register-resident variant for m <= EPT * 1024: every thread owns EPT fixed labels
+// and keeps their four statistics in registers across the whole sweep, so a row costs
+// one coalesced read of (eta, pred), the gains, k x 2 block reductions and the
+// prediction stores -- no statistics traffic, no gains workspace.  Same operation
+// order per label as the reference (bit-identical running statistics).
+template <typename T, int EPT>
+__global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_reg_kernel(DenseSweepParams<T> P) {
+    __shared__ unsigned long long red64[XC_DENSE_BLOCK / XC_WAVE];
+    __shared__ unsigned red32[XC_DENSE_BLOCK / XC_WAVE];
+    const int64_t m = P.m;
+    const double nn = P.nn;
+    const T one = (T)1;
+    double tp[EPT], fp[EPT], fn[EPT], tn[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+        const bool v = j < m;
+        tp[e] = v ? P.tp[j] : 0.0;
+        fp[e] = v ? P.fp[j] : 0.0;
+        fn[e] = v ? P.fn[j] : 0.0;
+        tn[e] = v ? P.tn[j] : 0.0;
+    }
+    auto row_of = [&](int64_t pos) -> int64_t {
+        const int64_t q = pos < P.n_order ? pos : P.n_order - 1;
+        return P.order ? (int64_t)P.order[q] : q;
+    };
+    T t_cur[EPT], p_cur[EPT];
+    {
+        const int64_t row = row_of(0);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+            t_cur[e] = j < m ? P.y_proba[row * m + j] : (T)0;
+            p_cur[e] = j < m ? P.y_pred[row * m + j] : (T)0;
+        }
+    }
+    for (int64_t pos = 0; pos < P.n_order; ++pos) {
+        const int64_t row = row_of(pos);
+        T *pred = P.y_pred + row * m;
+        // prefetch the next row (a row is visited once per sweep, so its prediction is
+        // not being rewritten meanwhile)
+        const int64_t nrow = row_of(pos + 1);
+        T t_nxt[EPT], p_nxt[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+            t_nxt[e] = j < m ? P.y_proba[nrow * m + j] : (T)0;
+            p_nxt[e] = j < m ? P.y_pred[nrow * m + j] : (T)0;
+        }
+
+        unsigned long long keys[EPT];
+        bool nonneg[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+            const T t = t_cur[e], p = p_cur[e];
+            const T om = one - t;
+            if (!P.greedy) { // block_coordinate.py:157-163
+                tp[e] -= (double)(T)(p * t);
+                fp[e] -= (double)(T)(p * om);
+                fn[e] -= (double)(T)((one - p) * t);
+                if (!P.skip_tn) tn[e] -= (double)(T)((one - p) * om);
+            }
+            // :166-185
+            const double pos_tp = tp[e] + (double)t;
+            const double pos_fp = fp[e] + (double)om;
+            const double neg_fn = fn[e] + (double)t;
+            double neg_tn = tn[e];
+            if (!P.skip_tn) neg_tn = tn[e] + (double)om;
+            double g = metric_eval(P.metric, pos_tp / nn, pos_fp / nn, fn[e] / nn, tn[e] / nn) -
+                       metric_eval(P.metric, tp[e] / nn, fp[e] / nn, neg_fn / nn, neg_tn / nn);
+            if (!P.maximize) g = -g;
+            keys[e] = j < m ? sortable_key(nan_to_neg_inf(g)) : 0ull;
+            nonneg[e] = (-g) <= 0.0; // :199-200 on the negated gains (k == 0)
+        }
+
+        unsigned long long mine = 0ull;
+        if (P.k > 0) {
+            unsigned long long prev_key = ~0ull;
+            unsigned prev_col = 0u;
+            bool first = true;
+            const int rounds = (int64_t)P.k < m ? P.k : (int)m;
+            for (int round = 0; round < rounds; ++round) {
+                unsigned long long best = 0ull;
+                unsigned col = ~0u;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const unsigned j = threadIdx.x + e * XC_DENSE_BLOCK;
+                    const bool rem = first || keys[e] < prev_key || (keys[e] == prev_key && j > prev_col);
+                    if (rem && keys[e] > best) best = keys[e];
+                }
+                best = block_umax64<XC_DENSE_BLOCK>(best, red64);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const unsigned j = threadIdx.x + e * XC_DENSE_BLOCK;
+                    const bool rem = first || keys[e] < prev_key || (keys[e] == prev_key && j > prev_col);
+                    if (rem && keys[e] == best && j < col) col = j;
+                }
+                col = block_umin32<XC_DENSE_BLOCK>(col, red32);
+                if ((col % XC_DENSE_BLOCK) == threadIdx.x) mine |= 1ull << (col / XC_DENSE_BLOCK);
+                prev_key = best;
+                prev_col = col;
+                first = false;
+            }
+        }
+
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+            const bool sel = P.k > 0 ? (((mine >> e) & 1ull) != 0ull) : nonneg[e];
+            const T t = t_cur[e];
+            const T p = sel ? one : (T)0;
+            const T om = one - t;
+            if (j < m) {
+                if (p != p_cur[e]) pred[j] = p; // :191-200
+                // :203-209
+                tp[e] += (double)(T)(p * t);
+                fp[e] += (double)(T)(p * om);
+                fn[e] += (double)(T)((one - p) * t);
+                if (!P.skip_tn) tn[e] += (double)(T)((one - p) * om);
+            }
+            t_cur[e] = t_nxt[e];
+            p_cur[e] = p_nxt[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+        if (j < m) {
+            P.tp[j] = tp[e];
+            P.fp[j] = fp[e];
+            P.fn[j] = fn[e];
+            P.tn[j] = tn[e];
+        }
     }
 }
 
@@ -263,12 +420,18 @@ int xc_bca_sweep_dense(int64_t n_order, const int32_t *order, int64_t n_norm, in
         xc::DenseSweepParams<float> P{n_order, order, m, static_cast<const float *>(y_proba), static_cast<float *>(y_pred), k,
                                       stats, stats + m, stats + 2 * m, stats + 3 * m, workspace, *metric_host,
                                       (double)n_norm, maximize, greedy, skip_tn};
-        hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<float>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        if (m <= 1 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_reg_kernel<float, 1>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        else if (m <= 4 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_reg_kernel<float, 4>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        else if (m <= 8 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_reg_kernel<float, 8>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        else hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<float, 0>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
     } else {
         xc::DenseSweepParams<double> P{n_order, order, m, static_cast<const double *>(y_proba), static_cast<double *>(y_pred), k,
                                        stats, stats + m, stats + 2 * m, stats + 3 * m, workspace, *metric_host,
                                        (double)n_norm, maximize, greedy, skip_tn};
-        hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<double>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        if (m <= 1 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_reg_kernel<double, 1>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        else if (m <= 4 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_reg_kernel<double, 4>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        else if (m <= 8 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_reg_kernel<double, 8>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
+        else hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<double, 0>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
     }
     XC_CHECK_LAUNCH("bca_sweep_dense_kernel");
     return XC_OK;
