@@ -499,3 +499,46 @@ def test_bca_csr_north_star_size_properties():
     assert (chosen.sum(axis=1) == k).all()
     data = Y.data.reshape(n, r)
     assert (np.where(chosen, data, np.inf).min(axis=1) >= np.where(~chosen, data, -np.inf).max(axis=1)).all()
+
+
+# ---------------------------------------------------------------------------
+# edges: empty input, maximum row length, limits
+# ---------------------------------------------------------------------------
+
+def test_edges_and_limits(oref):
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    from xcolumns_amd.weighted_prediction import predict_top_k, predict_weighted_per_instance
+    # no rows / rows without entries
+    E = csr_matrix((0, 7), dtype=np.float32)
+    P = predict_top_k(E, 3)
+    assert P.shape == (0, 7) and P.nnz == 0
+    Z = csr_matrix((5, 7), dtype=np.float32)       # five empty rows: the reference's padding (column 0, value 1)
+    _same_csr(predict_top_k(Z, 2), oref.predict_top_k(Z, 2))
+    # maximum row length handled in registers: exactly 1024 entries
+    rng = np.random.default_rng(0)
+    m = 4096
+    rows = [np.sort(rng.choice(m, l, replace=False)) for l in (1024, 1023, 5, 1024)]
+    indptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int32)
+    Y = csr_matrix((rng.random(indptr[-1]).astype(np.float32), np.concatenate(rows).astype(np.int32), indptr), shape=(4, m))
+    _same_csr(predict_top_k(Y, 5), oref.predict_top_k(Y, 5))
+    metric = oref.make_metric(oref.FBETA, k=5.0, m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, 5, skip_tn=True, seed=1, max_iters=2, tolerance=-1.0)
+    Pg, mg = predict_optimizing_macro_f1_score_using_bc(Y, 5, seed=1, max_iters=2, tolerance=-1.0, return_meta=True, bca_waves=1)
+    assert np.allclose(mg["utilities"], mo["utilities"], rtol=0, atol=1e-12) and np.array_equal(Pg.indices, Po.indices)
+    # one entry more than the limit: a clear error, no silent truncation
+    big = np.sort(rng.choice(m, 1025, replace=False)).astype(np.int32)
+    B = csr_matrix((rng.random(1025).astype(np.float32), big, np.array([0, 1025], dtype=np.int32)), shape=(1, m))
+    with pytest.raises(ValueError, match="1025"):
+        predict_top_k(B, 5)
+    with pytest.raises(ValueError):
+        predict_weighted_per_instance(Y, 65)                      # k above XC_MAX_K
+    with pytest.raises(ValueError, match="at least k"):
+        predict_optimizing_macro_f1_score_using_bc(Y, 6)          # a row stores only 5 entries
+    with pytest.raises(NotImplementedError):
+        predict_optimizing_macro_f1_score_using_bc(Y, 0)          # CSR k = 0
+    # int64 index arrays are accepted; the result carries the input's index dtype
+    # (scipy itself narrows to int32 when the values fit)
+    Y64 = csr_matrix((Y.data, Y.indices.astype(np.int64), Y.indptr.astype(np.int64)), shape=Y.shape)
+    P64 = predict_top_k(Y64, 5)
+    assert P64.indices.dtype == Y64.indices.dtype and P64.indptr.dtype == Y64.indptr.dtype
+    assert np.array_equal(P64.indices, predict_top_k(Y, 5).indices)
