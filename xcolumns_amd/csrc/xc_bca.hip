@@ -164,21 +164,19 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     // urgent, and vmcnt retires in issue order: issued right after the decision it
     // would sit in front of the NEXT row's gathers and their wait would pay the
     // atomics' ~700-cycle round trip.  So a row's acc atomics are issued one
-    // iteration later, just after the next row's gathers.
-    int pend_idx[CH];
-    T pend_eta[CH];
-    bool pend_on[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) { pend_idx[c] = 0; pend_eta[c] = (T)0; pend_on[c] = false; }
+    // iteration later, just after the next row's gathers.  They are also packed:
+    // the (label, eta) of the q-th predicted entry is moved (through LDS) to lanes
+    // 2q and 2q+1, which add eta and 1-eta to the label's two ADJACENT float64 slots
+    // in ONE wave instruction -- one 16-byte request per label at the memory-side
+    // atomic units instead of two (they are request-bound: ~21 G scattered/s).
+    __shared__ int s_pack_idx[XC_BLOCK / XC_WAVE][XC_MAX_K];
+    __shared__ T s_pack_eta[XC_BLOCK / XC_WAVE][XC_MAX_K];
+    const int wib = threadIdx.x >> 6;
+    int pend_idx = 0;      // lane L < 2 * pend_n: label of predicted entry L / 2
+    double pend_val = 0.0; // eta (even lane) or 1 - eta (odd lane)
+    int pend_n = 0;
     auto flush_pending = [&]() {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (pend_on[c]) {
-                double *a = P.acc + (int64_t)pend_idx[c] * 2;
-                atomic_add_f64(a + 0, (double)pend_eta[c]);
-                atomic_add_f64(a + 1, (double)((T)1 - pend_eta[c]));
-            }
-        }
+        if (lane < 2 * pend_n) atomic_add_f64(P.acc + (int64_t)pend_idx * 2 + (lane & 1), pend_val);
     };
 
     XC_STAMP_DECL;
@@ -418,11 +416,26 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // tp / fp of the new prediction summed over ALL rows) is accumulated row by row
         // instead of by a separate pass over the prediction afterwards; the atomics
         // themselves go out in the next iteration (flush_pending).
+        if (P.acc) {
+            int nsel = 0;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            pend_idx[c] = cur.idx[c];
-            pend_eta[c] = cur.eta[c];
-            pend_on[c] = in_new[c];
+            for (int c = 0; c < CH; ++c) {
+                const unsigned long long mask = __ballot(in_new[c]);
+                if (in_new[c]) {
+                    const int slot = nsel + __popcll(mask & lanemask_lt());
+                    s_pack_idx[wib][slot] = cur.idx[c];
+                    s_pack_eta[wib][slot] = cur.eta[c];
+                }
+                nsel += __popcll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            pend_n = nsel;
+            const int q = (lane >> 1) < nsel ? (lane >> 1) : 0;
+            pend_idx = s_pack_idx[wib][q];
+            const T e = s_pack_eta[wib][q];
+            pend_val = (lane & 1) ? (double)((T)1 - e) : (double)e;
         }
         if (row_changed || greedy) {
             int base = 0;
