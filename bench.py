@@ -136,11 +136,13 @@ def main():
         """One BCA iteration exactly as predict_using_bc_with_0approx runs it."""
         n_waves = policy.next(state["changed"])
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            # HIP events attached to the sweep dispatch itself, on the stream it runs on
+            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.call("xc_event_create", ctypes.byref(e0))
+            _lib.call("xc_event_create", ctypes.byref(e1))
+            _lib.call("xc_bca_time_next_sweep", e0, e1)
         eng.sweep(orders[s], n, n_waves, greedy=False)
         if timed:
-            e1.record()
             ev_pairs.append((e0, e1))
             waves_used.append(n_waves)
         u = eng.recompute_utility_sum(n_u) / m
@@ -173,7 +175,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    sweep_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+    sweep_ms = []
+    for a, b in ev_pairs:
+        ms = ctypes.c_float(0.0)
+        _lib.call("xc_event_elapsed_ms", a, b, ctypes.byref(ms))
+        sweep_ms.append(ms.value)
+        _lib.call("xc_event_destroy", a)
+        _lib.call("xc_event_destroy", b)
     avg_sweep_s = (sum(sweep_ms) / len(sweep_ms)) / 1e3 if sweep_ms else float("nan")
 
     if rank == 0:

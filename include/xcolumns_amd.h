@@ -240,6 +240,16 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      const double *s_entry, double *acc, const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
+/* Measurement helpers (bench.py).  HIP events owned by the library; the pair given to
+ * xc_bca_time_next_sweep is attached to the NEXT xc_bca_sweep_csr dispatch of the calling
+ * thread (hipExtLaunchKernelGGL start/stop events), so xc_event_elapsed_ms returns the
+ * kernel's own duration on its stream -- what rocprofv3 --kernel-trace reports --
+ * rather than kernel + dispatch gap. */
+int xc_event_create(void **ev);
+int xc_event_destroy(void *ev);
+int xc_event_elapsed_ms(void *start, void *stop, float *ms_host);
+int xc_bca_time_next_sweep(void *start, void *stop);
+
 /* Concurrent sweeps re-read, before committing a changed row, the records of the
  * labels it adds or drops and re-score the row if another wavefront moved them
  * (optimistic validation; default on).  Process-wide switch, mainly for studies. */

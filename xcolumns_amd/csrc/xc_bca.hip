@@ -28,6 +28,8 @@
 // pace, so a row misses at most the updates of the ~n_waves rows around it in
 // the order.  n_waves = 1 is the exact sequential sweep (used by the parity
 // tests); the driver picks n_waves as a small fraction of n.
+#include <hip/hip_ext.h>
+
 #include "xc_common.h"
 #include "xc_host.h"
 
@@ -635,17 +637,32 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
 }
 
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
+// one-shot HIP events recorded tightly around the NEXT sweep launch (xc_bca_time_next_sweep)
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_validate = 1;                           // xc_bca_set_validation
+
+template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW>
+static void launch_sweep_one(const SweepParams<T> &P, hipStream_t st) {
+    const int blocks = (P.n_waves + 3) / 4;
+    if (g_ev_start && g_ev_stop) {
+        // start / stop events attached to the dispatch itself: the measured span is the
+        // kernel, not the kernel plus the dispatch gap an event pair around it would add
+        hipExtLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st,
+                              g_ev_start, g_ev_stop, 0, P);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P);
+    }
+}
 
 template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW>
 static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
-    const int blocks = (P.n_waves + 3) / 4;
     switch (ch) {
-    case 1: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 1, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 2: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 2, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 4: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 4, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    case 8: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 8, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
-    default: hipLaunchKernelGGL((bca_sweep_csr_kernel<T, 16, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P); break;
+    case 1: launch_sweep_one<T, 1, EXACT, HAS_ORDER, SHADOW>(P, st); break;
+    case 2: launch_sweep_one<T, 2, EXACT, HAS_ORDER, SHADOW>(P, st); break;
+    case 4: launch_sweep_one<T, 4, EXACT, HAS_ORDER, SHADOW>(P, st); break;
+    case 8: launch_sweep_one<T, 8, EXACT, HAS_ORDER, SHADOW>(P, st); break;
+    default: launch_sweep_one<T, 16, EXACT, HAS_ORDER, SHADOW>(P, st); break;
     }
 }
 
@@ -828,6 +845,33 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
         xc::launch_sweep<double>(P, ch, st);
     }
     XC_CHECK_LAUNCH("bca_sweep_csr_kernel");
+    return XC_OK;
+}
+
+// ---- measurement helpers (bench.py): HIP events owned by the library ---------------
+int xc_event_create(void **ev) {
+    if (!ev) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_event_create: NULL");
+    hipEvent_t e;
+    XC_HIP_TRY(hipEventCreate(&e));
+    *ev = e;
+    return XC_OK;
+}
+
+int xc_event_destroy(void *ev) {
+    if (ev) XC_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(ev)));
+    return XC_OK;
+}
+
+int xc_event_elapsed_ms(void *start, void *stop, float *ms_host) {
+    if (!start || !stop || !ms_host) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_event_elapsed_ms: NULL");
+    XC_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+    XC_HIP_TRY(hipEventElapsedTime(ms_host, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return XC_OK;
+}
+
+int xc_bca_time_next_sweep(void *start, void *stop) {
+    xc::g_ev_start = static_cast<hipEvent_t>(start);
+    xc::g_ev_stop = static_cast<hipEvent_t>(stop);
     return XC_OK;
 }
 
