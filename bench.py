@@ -131,22 +131,33 @@ def main():
     ev_pairs = []
     waves_used = []
     state = {"changed": None}
+    # events are created up front: only their attachment to the sweep dispatch is in the timed region
+    ev_pool = []
+    for _ in range(args.steps):
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call("xc_event_create", ctypes.byref(e0))
+        _lib.call("xc_event_create", ctypes.byref(e1))
+        ev_pool.append((e0, e1))
+    host_t = {"sweep_call": 0.0, "boundary_call": 0.0}
 
     def step(s, timed):
         """One BCA iteration exactly as predict_using_bc_with_0approx runs it."""
         n_waves = policy.next(state["changed"])
         if timed:
             # HIP events attached to the sweep dispatch itself, on the stream it runs on
-            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-            _lib.call("xc_event_create", ctypes.byref(e0))
-            _lib.call("xc_event_create", ctypes.byref(e1))
+            e0, e1 = ev_pool[len(ev_pairs)]
             _lib.call("xc_bca_time_next_sweep", e0, e1)
+        t_a = time.perf_counter()
         eng.sweep(orders[s], n, n_waves, greedy=False)
+        t_b = time.perf_counter()
         if timed:
             ev_pairs.append((e0, e1))
             waves_used.append(n_waves)
         u = eng.recompute_utility_sum(n_u) / m
         state["changed"] = eng.rows_changed()
+        if timed:
+            host_t["sweep_call"] += t_b - t_a
+            host_t["boundary_call"] += time.perf_counter() - t_b
         return u
 
     utilities = []
@@ -228,6 +239,8 @@ def main():
                 "algorithmic_bytes_per_row": b_step,
                 "avg_kernel_ms": avg_sweep_s * 1e3,
             },
+            "host_ms_per_step": {"sweep_launch_call": host_t["sweep_call"] / args.steps * 1e3,
+                                 "boundary_call_incl_wait_for_sweep": host_t["boundary_call"] / args.steps * 1e3},
             "utility_first_last": [utilities[0], utilities[-1]],
             "utility_top_k": u0,
         }

@@ -240,6 +240,27 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      const double *s_entry, double *acc, const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
+/* Plan: bind the per-run constants of a CSR BCA once; afterwards a sweep and its boundary
+ * are two short calls (same kernels as xc_bca_sweep_csr / xc_bca_commit_utility +
+ * xc_utility_finish_host; it only saves argument marshalling in the host language).
+ * The buffers stay owned by the caller and must outlive the plan. */
+int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total,
+                       const int32_t *indptr, const int32_t *indices, const void *data,
+                       int dtype, int max_row_nnz, int k, int32_t *pred_indices,
+                       void *pred_eta, uint8_t *sel, double *tpfp, float *shadow,
+                       double *colsum, const double *s_entry, double *acc, double *partials,
+                       const xc_metric *gain_metric, const xc_metric *utility_metric,
+                       int maximize, int skip_tn);
+int xc_bca_plan_destroy(void *plan);
+/* with_acc: accumulate the new prediction into acc (pass 1 when every row is visited) */
+int xc_bca_plan_sweep(void *plan, const int32_t *order, int64_t n_order,
+                      const int32_t *orphans, int greedy, int n_waves, int with_acc,
+                      int64_t *changed, void *stream);
+/* commit (acc -> tpfp / shadow, clear acc) when `commit`, utility partials, blocking D2H */
+int xc_bca_plan_boundary(void *plan, int64_t n_norm_utility, double n_counted, int commit,
+                         int skip_tn, double *out_sum_host, double *out_extra_host,
+                         void *stream);
+
 /* Measurement helpers (bench.py).  HIP events owned by the library; the pair given to
  * xc_bca_time_next_sweep is attached to the NEXT xc_bca_sweep_csr dispatch of the calling
  * thread (hipExtLaunchKernelGGL start/stop events), so xc_event_elapsed_ms returns the

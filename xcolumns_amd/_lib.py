@@ -70,6 +70,13 @@ SIGNATURES = {
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, POINTER(XcMetric),
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xc_bca_plan_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, POINTER(XcMetric), POINTER(XcMetric), c_int, c_int]),
+    "xc_bca_plan_destroy": (c_int, [c_void_p]),
+    "xc_bca_plan_sweep": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xc_bca_plan_boundary": (c_int, [c_void_p, c_int64, c_double, c_int, c_int, POINTER(c_double), POINTER(c_double),
+                                     c_void_p]),
     "xc_bca_set_validation": (c_int, [c_int]),
     "xc_event_create": (c_int, [POINTER(c_void_p)]),
     "xc_event_destroy": (c_int, [c_void_p]),

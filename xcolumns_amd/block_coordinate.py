@@ -168,6 +168,34 @@ class BcaCsrEngine:
                   D.stream())
         self.orphans = orphans if bool((orphans >= 0).any().item()) else None
 
+    # -- plan: per-run constants bound once on the C side ------------------------------
+    def _plan_handle(self):
+        """(Re)bind when the prediction buffers were replaced by an init_* call."""
+        key = (self.pred_idx.data_ptr(), self.pred_eta.data_ptr())
+        if getattr(self, "_plan_key", None) != key:
+            self._drop_plan()
+            h = ctypes.c_void_p()
+            c = self.csr
+            _lib.call("xc_bca_plan_create", ctypes.byref(h), c.n, c.m, self.n_total, D.ptr(c.indptr), D.ptr(c.indices),
+                      D.ptr(c.data), c.code, int(c.max_row_nnz), self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
+                      D.ptr(self.sel), D.ptr(self.tpfp), D.ptr(self.shadow), D.ptr(self.colsum), D.ptr(self.s_entry),
+                      D.ptr(self.acc), D.ptr(self.partials), ctypes.byref(self.gain_metric),
+                      ctypes.byref(self.utility_metric), int(self.maximize), int(self.skip_tn))
+            self._plan, self._plan_key = h, key
+        return self._plan
+
+    def _drop_plan(self):
+        if getattr(self, "_plan", None) is not None:
+            _lib.load().xc_bca_plan_destroy(self._plan)
+            self._plan = None
+            self._plan_key = None
+
+    def __del__(self):
+        try:
+            self._drop_plan()
+        except Exception:
+            pass
+
     # -- statistics -------------------------------------------------------------
     def reset_state(self, greedy: bool):
         """Zero the statistics; unless `greedy`, colsum <- column sums of y_proba over
@@ -214,13 +242,11 @@ class BcaCsrEngine:
 
     def utility_sum(self, n_norm_utility: int, commit: bool = False, n_counted: Optional[float] = None,
                     skip_tn: Optional[bool] = None) -> float:
-        _lib.call("xc_bca_commit_utility", self.csr.m, int(n_norm_utility),
-                  float(self.n_total if n_counted is None else n_counted),
-                  D.ptr(self.acc) if commit else None, 1, D.ptr(self.tpfp), D.ptr(self.shadow), D.ptr(self.colsum),
-                  ctypes.byref(self.utility_metric),
-                  int(self.skip_tn if skip_tn is None else skip_tn), D.ptr(self.partials), D.stream())
         out, extra = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        _lib.call("xc_utility_finish_host", D.ptr(self.partials), ctypes.byref(out), ctypes.byref(extra), D.stream())
+        _lib.call("xc_bca_plan_boundary", self._plan_handle(), int(n_norm_utility),
+                  float(self.n_total if n_counted is None else n_counted), int(bool(commit)),
+                  int(self.skip_tn if skip_tn is None else skip_tn), ctypes.byref(out), ctypes.byref(extra),
+                  D.stream())
         if commit:
             self._changed_last = int(round(extra.value))
         return out.value
@@ -235,12 +261,8 @@ class BcaCsrEngine:
         full = n_order >= c.n
         if not full:
             self.changed.zero_()
-        _lib.call("xc_bca_sweep_csr", int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
-                  D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx),
-                  D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(self.orphans), self.k, int(c.m), D.ptr(self.tpfp),
-                  D.ptr(self.shadow), D.ptr(self.colsum), D.ptr(self.s_entry), D.ptr(self.acc) if full else None,
-                  ctypes.byref(self.gain_metric), int(self.maximize), int(bool(greedy)), int(self.skip_tn),
-                  int(n_waves), None if full else D.ptr(self.changed), D.stream())
+        _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(order), int(n_order), D.ptr(self.orphans),
+                  int(bool(greedy)), int(n_waves), int(full), None if full else D.ptr(self.changed), D.stream())
         self._acc_filled = full
         self._partial_sweep = not full
         # every row was visited: no orphan is left in any prediction

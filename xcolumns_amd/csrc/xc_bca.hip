@@ -887,6 +887,62 @@ int xc_debug_set_stamp_buffer(void *buf) {
     return XC_OK;
 }
 
+// ---- plan: the per-run constants bound once, two short calls per sweep --------------
+struct xc_bca_plan_s {
+    int64_t n, m, n_total;
+    const int32_t *indptr, *indices;
+    const void *data;
+    int dtype, max_row_nnz, k;
+    int32_t *pred_indices;
+    void *pred_eta;
+    uint8_t *sel;
+    double *tpfp;
+    float *shadow;
+    double *colsum;
+    const double *s_entry;
+    double *acc, *partials;
+    xc_metric gain_metric, utility_metric;
+    int maximize, skip_tn;
+};
+
+int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total, const int32_t *indptr,
+                       const int32_t *indices, const void *data, int dtype, int max_row_nnz, int k,
+                       int32_t *pred_indices, void *pred_eta, uint8_t *sel, double *tpfp, float *shadow,
+                       double *colsum, const double *s_entry, double *acc, double *partials,
+                       const xc_metric *gain_metric, const xc_metric *utility_metric, int maximize, int skip_tn) {
+    if (!plan || !gain_metric || !utility_metric) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_create: NULL pointer");
+    xc_bca_plan_s *p = new xc_bca_plan_s{n, m, n_total, indptr, indices, data, dtype, max_row_nnz, k, pred_indices,
+                                         pred_eta, sel, tpfp, shadow, colsum, s_entry, acc, partials, *gain_metric,
+                                         *utility_metric, maximize, skip_tn};
+    *plan = p;
+    return XC_OK;
+}
+
+int xc_bca_plan_destroy(void *plan) {
+    delete static_cast<xc_bca_plan_s *>(plan);
+    return XC_OK;
+}
+
+int xc_bca_plan_sweep(void *plan, const int32_t *order, int64_t n_order, const int32_t *orphans, int greedy,
+                      int n_waves, int with_acc, int64_t *changed, void *stream) {
+    if (!plan) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep: NULL plan");
+    const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
+    return xc_bca_sweep_csr(n_order, order, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
+                            p->pred_indices, p->pred_eta, p->sel, orphans, p->k, p->m, p->tpfp, p->shadow, p->colsum,
+                            p->s_entry, with_acc ? p->acc : nullptr, &p->gain_metric, p->maximize, greedy, p->skip_tn,
+                            n_waves, changed, stream);
+}
+
+int xc_bca_plan_boundary(void *plan, int64_t n_norm_utility, double n_counted, int commit, int skip_tn,
+                         double *out_sum_host, double *out_extra_host, void *stream) {
+    if (!plan) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_boundary: NULL plan");
+    const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
+    int rc = xc_bca_commit_utility(p->m, n_norm_utility, n_counted, commit ? p->acc : nullptr, 1, p->tpfp, p->shadow,
+                                   p->colsum, &p->utility_metric, skip_tn, p->partials, stream);
+    if (rc) return rc;
+    return xc_utility_finish_host(p->partials, out_sum_host, out_extra_host, stream);
+}
+
 int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum, double n_counted, int skip_tn,
                         double *tp, double *fp, double *fn, double *tn, void *stream) {
     if (m < 0 || !tpfp || !colsum || !tp || !fp || !fn || !tn)
