@@ -391,7 +391,39 @@ def gen_bca_dense():
         save("bca_dense_" + tag, **out)
 
 
+# ---------------------------------------------------------------------------
+# F. evaluation metrics on true labels (metrics.py:38-224 factories)
+# ---------------------------------------------------------------------------
+
+EVAL_NAMES = [f"{avg}_{stem}" for stem in ("precision", "recall", "f1_score", "fbeta_score", "jaccard_score",
+                                            "balanced_accuracy", "gmean", "hmean")
+              for avg in ("macro", "micro", "instance")]
+
+
+def gen_eval():
+    rng = np.random.default_rng(601)
+    n, m, k = 500, 60, 4
+    Yp = fixed_csr(rng, n, m, 15, np.float64, zipf=True, skew=True)
+    P = predict_weighted_per_instance(Yp, k)
+    L = ragged_csr(rng, n, m, 7, np.float64, zipf=True)
+    L.data[:] = 1
+    out = {}
+    out.update(csr_fields("l", L))
+    out.update(csr_fields("p", P))
+    Ld, Pd = L.toarray(), P.toarray()
+    out["ld"], out["pd"] = Ld, Pd
+    for name in EVAL_NAMES:
+        # the reference spells one of them `instance_jaccard_score_score` (metrics.py:815)
+        f = getattr(ref_metrics, name, None) or getattr(ref_metrics, name + "_score")
+        out["csr_" + name] = np.float64(f(L, P))
+        out["dense_" + name] = np.float64(f(Ld, Pd))
+        assert abs(out["csr_" + name] - out["dense_" + name]) < 1e-12, name
+    out["names"] = np.asarray(EVAL_NAMES)
+    out["label_priors"] = np.asarray(ref_metrics.label_priors(Ld))
+    save("eval_f64", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense"]
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval"]
     for w in which:
         globals()["gen_" + w]()

@@ -542,3 +542,16 @@ def test_edges_and_limits(oref):
     P64 = predict_top_k(Y64, 5)
     assert P64.indices.dtype == Y64.indices.dtype and P64.indptr.dtype == Y64.indptr.dtype
     assert np.array_equal(P64.indices, predict_top_k(Y, 5).indices)
+
+
+def test_evaluation_metrics_golden():
+    """macro / micro / instance metrics on true labels against values the
+    reference itself produced; statistics come from the GPU confusion kernels."""
+    import xcolumns_amd.metrics as pm
+    z = G.load("eval_f64")
+    L, P = G.csr_from(z, "l"), G.csr_from(z, "p")
+    for name in [str(s) for s in z["names"]]:
+        f = getattr(pm, name)
+        assert abs(f(L, P) - float(z["csr_" + name])) < 1e-12, name
+        assert abs(f(z["ld"], z["pd"]) - float(z["dense_" + name])) < 1e-12, name
+    assert np.allclose(pm.label_priors(z["ld"]), z["label_priors"], rtol=0, atol=1e-15)

@@ -233,3 +233,115 @@ def host_values(spec: MetricSpec, tp, fp, fn, tn):
     if spec.mixed:
         return (1 - spec.alpha) * (tp / spec.kf) + spec.alpha * base / spec.mf
     return base
+
+
+# ---------------------------------------------------------------------------
+# Evaluation on true labels: the step right after prediction in
+# every driver of the reference.  The per-label / per-instance statistics come from
+# the fused GPU pass (xc_confusion_csr / xc_confusion_dense); the O(m) or O(n)
+# arithmetic on them stays on the host, as in /root/reference/xcolumns/metrics.py
+# (:38-224 factories, :284-328 label statistics).
+# ---------------------------------------------------------------------------
+
+def _with_kwargs_of(func: Callable, source: Callable) -> Callable:
+    from .utils import add_kwargs_to_signature
+
+    return add_kwargs_to_signature(func, source)
+
+
+def make_macro_metric_on_conf_matrix(binary_metric: Callable, name: str) -> Callable:
+    """Mean over labels of `binary_metric(tp, fp, fn, tn, **kwargs)`."""
+
+    def macro_metric_on_conf_matrix(tp, fp, fn, tn, **kwargs):
+        return binary_metric(tp, fp, fn, tn, **kwargs).mean()
+
+    macro_metric_on_conf_matrix.__doc__ = f"Macro-averaged {name}: the mean of {binary_metric.__name__} over labels."
+    return _with_kwargs_of(macro_metric_on_conf_matrix, binary_metric)
+
+
+def make_micro_metric_on_conf_matrix(binary_metric: Callable, name: str) -> Callable:
+    """`binary_metric` of the label-summed entries."""
+
+    def micro_metric_on_conf_matrix(tp, fp, fn, tn, **kwargs):
+        return binary_metric(tp.sum(), fp.sum(), fn.sum(), tn.sum(), **kwargs)
+
+    micro_metric_on_conf_matrix.__doc__ = f"Micro-averaged {name}: {binary_metric.__name__} of the summed entries."
+    return _with_kwargs_of(micro_metric_on_conf_matrix, binary_metric)
+
+
+def make_metric_on_y_true_and_y_pred(metric_on_conf_matrix: Callable, metric_name: str,
+                                     skip_tn: bool = False) -> Callable:
+    """metric(y_true, y_pred, **kwargs) from metric(tp, fp, fn, tn, **kwargs): per-label
+    rates (normalised confusion matrix, axis 0) from one GPU pass."""
+
+    def metric_on_y_true_and_y_pred(y_true, y_pred, **kwargs):
+        from .confusion_matrix import calculate_confusion_matrix
+
+        C = calculate_confusion_matrix(y_true, y_pred, normalize=True, skip_tn=skip_tn, axis=0)
+        return metric_on_conf_matrix(*C, **kwargs)
+
+    metric_on_y_true_and_y_pred.__doc__ = f"{metric_name} of `y_pred` against `y_true` ({metric_on_conf_matrix.__name__})."
+    return _with_kwargs_of(metric_on_y_true_and_y_pred, metric_on_conf_matrix)
+
+
+def make_instance_metric_on_y_true_and_y_pred(binary_metric: Callable, metric_name: str,
+                                              skip_tn: bool = False) -> Callable:
+    """Instance-averaged metric: `binary_metric` on every row's counts (axis 1), then the mean."""
+
+    def instance_metric_on_y_true_and_y_pred(y_true, y_pred, **kwargs):
+        from .confusion_matrix import calculate_confusion_matrix
+
+        C = calculate_confusion_matrix(y_true, y_pred, normalize=False, skip_tn=skip_tn, axis=1)
+        return binary_metric(*C, **kwargs).mean()
+
+    instance_metric_on_y_true_and_y_pred.__doc__ = f"Instance-averaged {metric_name} ({binary_metric.__name__} per row)."
+    return _with_kwargs_of(instance_metric_on_y_true_and_y_pred, binary_metric)
+
+
+def _publish_metric_family():
+    """macro_* / micro_* / instance_* / binary_* evaluation functions for each formula,
+    named as in the reference (metrics.py:608-623 and its siblings)."""
+    family = {
+        "precision": (binary_precision_on_conf_matrix, True),
+        "recall": (binary_recall_on_conf_matrix, True),
+        "fbeta_score": (binary_fbeta_score_on_conf_matrix, True),
+        "f1_score": (binary_f1_score_on_conf_matrix, True),
+        "jaccard_score": (binary_jaccard_score_on_conf_matrix, True),
+        "balanced_accuracy": (binary_balanced_accuracy_on_conf_matrix, False),
+        "gmean": (binary_gmean_on_conf_matrix, False),
+        "hmean": (binary_hmean_on_conf_matrix, False),
+    }
+    g = globals()
+    for stem, (binary, skip_tn) in family.items():
+        label = stem.replace("_", " ")
+        macro_cm = make_macro_metric_on_conf_matrix(binary, label)
+        micro_cm = make_micro_metric_on_conf_matrix(binary, label)
+        macro_cm.__name__ = f"macro_{stem}_on_conf_matrix"
+        micro_cm.__name__ = f"micro_{stem}_on_conf_matrix"
+        g[macro_cm.__name__] = macro_cm
+        g[micro_cm.__name__] = micro_cm
+        g[f"binary_{stem}"] = make_metric_on_y_true_and_y_pred(binary, f"binary {label}", skip_tn=skip_tn)
+        g[f"macro_{stem}"] = make_metric_on_y_true_and_y_pred(macro_cm, f"macro-averaged {label}", skip_tn=skip_tn)
+        g[f"micro_{stem}"] = make_metric_on_y_true_and_y_pred(micro_cm, f"micro-averaged {label}", skip_tn=skip_tn)
+        g[f"instance_{stem}"] = make_instance_metric_on_y_true_and_y_pred(binary, label, skip_tn=skip_tn)
+
+
+_publish_metric_family()
+# the reference's own spelling of this one (metrics.py:815), kept so call sites keep working
+instance_jaccard_score_score = globals()["instance_jaccard_score"]
+
+
+def label_counts(y):
+    """Occurrences of each label (column sums)."""
+    if len(y.shape) > 2:
+        raise ValueError("y must be a binary matrix")
+    return y.sum(axis=0)
+
+
+def label_priors(y):
+    """Prior probability of each label: counts / number of rows."""
+    return label_counts(y) / y.shape[0]
+
+
+def inverse_label_priors(y):
+    return 1.0 / label_priors(y)
