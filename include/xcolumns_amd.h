@@ -77,6 +77,10 @@ typedef struct xc_metric {
  *                          so far (constant during a non-greedy sweep);
  *   s_entry float64[nnz]   colsum expanded per stored entry of y_proba, so it
  *                          streams in with the row instead of being gathered.
+ *   packed  16 B x nnz     optional (float32 scores): {col | sel << 31, eta, s} per
+ *                          stored entry -- indices, data, sel and s_entry interleaved,
+ *                          so a candidate streams in as ONE 16-byte lane load
+ *                          (xc_bca_pack_rows; the sweep keeps its sel bits current).
  *   shadow  float32[m][2]  optional rounded copy of tpfp (8-byte records): what the
  *                          CONCURRENT sweep gathers, so twice as many labels stay in
  *                          an XCD's 4 MiB L2; written by xc_bca_commit_utility, kept
@@ -153,6 +157,10 @@ int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_p
 
 /* ---- block coordinate ascent, CSR ------------------------------------- */
 
+/* packed[p] <- {indices[p] | sel[p] << 31, data[p], s_entry[p]} for float32 scores. */
+int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data,
+                     const uint8_t *sel, const double *s_entry, void *packed, void *stream);
+
 /* For a prediction given as column ids (pred_indices[n*k], k per row), look up
  * each id in its row of y_proba: pred_eta[n*k] <- the stored value, or 0 when the
  * row does not hold that column (the reference treats it as eta = 0,
@@ -220,6 +228,8 @@ int xc_utility_finish_host(const double *partials, double *out_host,
  *   shadow       optional float32 copy of tpfp (see above); NULL = gather tpfp
  *   s_entry      colsum per stored entry (xc_bca_expand_colsum); may be NULL when
  *                greedy (colsum is then gathered and grows during the sweep)
+ *   packed       optional packed row stream (float32 scores, non-greedy); NULL = read
+ *                indices / data / sel / s_entry separately
  *   acc          optional float64[2m + 1], zeroed by the caller: the sweep adds every
  *                visited row's NEW prediction into it ({tp, fp} per label) -- when
  *                all rows are visited this IS the sweep-boundary recompute
@@ -237,7 +247,8 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      int dtype, int max_row_nnz, int32_t *pred_indices,
                      void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
                      int64_t m, double *tpfp, float *shadow, double *colsum,
-                     const double *s_entry, double *acc, const xc_metric *metric_host, int maximize, int greedy,
+                     const double *s_entry, void *packed, double *acc,
+                     const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
 /* Plan: bind the per-run constants of a CSR BCA once; afterwards a sweep and its boundary
@@ -248,14 +259,14 @@ int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total,
                        const int32_t *indptr, const int32_t *indices, const void *data,
                        int dtype, int max_row_nnz, int k, int32_t *pred_indices,
                        void *pred_eta, uint8_t *sel, double *tpfp, float *shadow,
-                       double *colsum, const double *s_entry, double *acc, double *partials,
-                       const xc_metric *gain_metric, const xc_metric *utility_metric,
-                       int maximize, int skip_tn);
+                       double *colsum, const double *s_entry, void *packed, double *acc,
+                       double *partials, const xc_metric *gain_metric,
+                       const xc_metric *utility_metric, int maximize, int skip_tn);
 int xc_bca_plan_destroy(void *plan);
 /* with_acc: accumulate the new prediction into acc (pass 1 when every row is visited) */
 int xc_bca_plan_sweep(void *plan, const int32_t *order, int64_t n_order,
                       const int32_t *orphans, int greedy, int n_waves, int with_acc,
-                      int64_t *changed, void *stream);
+                      int use_packed, int64_t *changed, void *stream);
 /* commit (acc -> tpfp / shadow, clear acc) when `commit`, utility partials, blocking D2H */
 int xc_bca_plan_boundary(void *plan, int64_t n_norm_utility, double n_counted, int commit,
                          int skip_tn, double *out_sum_host, double *out_extra_host,

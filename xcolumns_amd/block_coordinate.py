@@ -137,6 +137,12 @@ class BcaCsrEngine:
         self.shadow = torch.zeros((m, 2), dtype=torch.float32, device=dev) if use_shadow else None
         self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
         self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
+        # float32 scores: indices / data / sel / s_entry interleaved in 16-byte entries, so a
+        # candidate streams in as one 16-byte lane load (XCOLUMNS_BCA_PACKED=0 disables)
+        self.packed = (torch.empty((max(1, csr.nnz), 4), dtype=torch.int32, device=dev)
+                       if csr.data.dtype == torch.float32 and os.environ.get("XCOLUMNS_BCA_PACKED", "1") != "0"
+                       else None)
+        self._pack_dirty = True
         # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count
         self.acc = torch.zeros(2 * m + 1, dtype=torch.float64, device=dev)
         self._acc_filled = False    # did the last sweep leave the new prediction's statistics in acc
@@ -154,6 +160,7 @@ class BcaCsrEngine:
         """predict_top_k (block_coordinate.py:40)."""
         self.pred_idx, _, self.pred_eta = topk_csr_device(self.csr, self.k, want_eta=True, out_sel=self.sel)
         self.orphans = None
+        self._pack_dirty = True
 
     def init_indices(self, pred_idx: torch.Tensor):
         """An explicit prediction: k column ids per row.  Columns a row does not store
@@ -167,6 +174,7 @@ class BcaCsrEngine:
                   D.ptr(self.pred_idx), self.k, D.ptr(self.pred_eta), D.ptr(self.sel), D.ptr(orphans),
                   D.stream())
         self.orphans = orphans if bool((orphans >= 0).any().item()) else None
+        self._pack_dirty = True
 
     # -- plan: per-run constants bound once on the C side ------------------------------
     def _plan_handle(self):
@@ -179,7 +187,7 @@ class BcaCsrEngine:
             _lib.call("xc_bca_plan_create", ctypes.byref(h), c.n, c.m, self.n_total, D.ptr(c.indptr), D.ptr(c.indices),
                       D.ptr(c.data), c.code, int(c.max_row_nnz), self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
                       D.ptr(self.sel), D.ptr(self.tpfp), D.ptr(self.shadow), D.ptr(self.colsum), D.ptr(self.s_entry),
-                      D.ptr(self.acc), D.ptr(self.partials), ctypes.byref(self.gain_metric),
+                      D.ptr(self.packed), D.ptr(self.acc), D.ptr(self.partials), ctypes.byref(self.gain_metric),
                       ctypes.byref(self.utility_metric), int(self.maximize), int(self.skip_tn))
             self._plan, self._plan_key = h, key
         return self._plan
@@ -216,6 +224,13 @@ class BcaCsrEngine:
         c = self.csr
         _lib.call("xc_bca_expand_colsum", c.nnz, D.ptr(c.indices), D.ptr(self.colsum), D.ptr(self.s_entry),
                   D.stream())
+        self._pack_dirty = True
+
+    def _repack(self):
+        c = self.csr
+        _lib.call("xc_bca_pack_rows", c.nnz, D.ptr(c.indices), D.ptr(c.data), D.ptr(self.sel), D.ptr(self.s_entry),
+                  D.ptr(self.packed), D.stream())
+        self._pack_dirty = False
 
     def sync_column_sums(self):
         """After a greedy sweep: colsum holds this rank's rows only -> all ranks;
@@ -261,8 +276,14 @@ class BcaCsrEngine:
         full = n_order >= c.n
         if not full:
             self.changed.zero_()
+        use_packed = self.packed is not None and not greedy
+        if use_packed and self._pack_dirty:
+            self._repack()
         _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(order), int(n_order), D.ptr(self.orphans),
-                  int(bool(greedy)), int(n_waves), int(full), None if full else D.ptr(self.changed), D.stream())
+                  int(bool(greedy)), int(n_waves), int(full), int(use_packed),
+                  None if full else D.ptr(self.changed), D.stream())
+        if greedy:
+            self._pack_dirty = True  # the greedy sweep rewrites sel without touching the packed copy
         self._acc_filled = full
         self._partial_sweep = not full
         # every row was visited: no orphan is left in any prediction

@@ -35,6 +35,8 @@
 
 namespace xc {
 
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
 template <typename T>
 struct SweepParams {
     int64_t n_order;
@@ -52,6 +54,8 @@ struct SweepParams {
                             // concurrent sweep (8-byte records: twice the labels per L2 byte)
     double *colsum;         // [m] s = tp + fn
     const double *s_entry;  // [nnz] colsum expanded per stored entry (NULL in the greedy sweep)
+    uint4_t *packed;        // optional [nnz] 16-byte entries {col | sel << 31, eta (f32), s (f64)}: the
+                            // row streams interleaved so a candidate is ONE 16-byte lane load
     double *acc;            // optional [2m + 1]: from-scratch {tp, fp} of the NEW prediction, [2m] += changed rows
     int64_t m;
     unsigned tpfp_bytes;
@@ -91,7 +95,6 @@ struct SweepParams {
 // The row a wavefront works on: everything that does not depend on the
 // statistics, so it can be fetched ahead of time.
 typedef double double2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 #define XC_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
@@ -109,7 +112,7 @@ struct RowData {
 // All lanes load (clamped to the row's last entry): straight-line code keeps the
 // loads in flight under precise vmcnt waits instead of exec-masked blocks; lanes
 // past the row end are masked out by `p < r` later.
-template <typename T, int CH>
+template <typename T, int CH, bool PACKED>
 __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, int lane, RowData<T, CH> &d) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -117,15 +120,25 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
         const int pc = p < r ? p : r - 1;
         // read-once streams: non-temporal, so they do not evict the {tp, fp} records
         // (the gather table) from the XCD's L2
-        d.idx[c] = __builtin_nontemporal_load(P.indices + s + pc);
-        d.eta[c] = __builtin_nontemporal_load(P.data + s + pc);
-        d.sel[c] = __builtin_nontemporal_load(P.sel + s + pc);
-        d.sc[c] = P.s_entry ? __builtin_nontemporal_load(P.s_entry + s + pc) : 0.0;
+        if (PACKED) {
+            // one 16-byte load per lane = 1 KiB per wave instruction, the widest shape
+            const uint4_t w = __builtin_nontemporal_load(P.packed + s + pc);
+            d.idx[c] = (int)(w.x & 0x7fffffffu);
+            d.sel[c] = (uint8_t)(w.x >> 31);
+            d.eta[c] = (T)__uint_as_float(w.y);
+            d.sc[c] = __longlong_as_double((long long)(((unsigned long long)w.w << 32) | w.z));
+        } else {
+            d.idx[c] = __builtin_nontemporal_load(P.indices + s + pc);
+            d.eta[c] = __builtin_nontemporal_load(P.data + s + pc);
+            d.sel[c] = __builtin_nontemporal_load(P.sel + s + pc);
+            d.sc[c] = P.s_entry ? __builtin_nontemporal_load(P.s_entry + s + pc) : 0.0;
+        }
     }
 }
 
 // SHADOW (only with !EXACT, never greedy): gather the float32 copy of the records.
-template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW>
+// PACKED (float32 scores, never greedy): the row streams come interleaved from `packed`.
+template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED>
 __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     int s0 = uni(P.indptr[row0]), e0 = uni(P.indptr[row0 + 1]);
     int s1 = uni(P.indptr[row1]), e1 = uni(P.indptr[row1 + 1]);
     RowData<T, CH> cur;
-    load_row<T, CH>(P, s0, e0 - s0, lane, cur);
+    load_row<T, CH, PACKED>(P, s0, e0 - s0, lane, cur);
     // The from-scratch accumulation of a row's new prediction into `acc` is not
     // urgent, and vmcnt retires in issue order: issued right after the decision it
     // would sit in front of the NEXT row's gathers and their wait would pay the
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // keeps hipcc from hoisting them above the gathers) ----
         __builtin_amdgcn_sched_barrier(0);
         RowData<T, CH> nxt;
-        load_row<T, CH>(P, s1, e1 - s1, lane, nxt);
+        load_row<T, CH, PACKED>(P, s1, e1 - s1, lane, nxt);
         const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
         const int row3 = row_at(pos + 3 * W);
         if (P.acc) flush_pending(); // the previous row's contribution to acc (younger than the gathers)
@@ -450,8 +463,12 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                     p_eta[slot] = cur.eta[c];
                 }
                 base += __popcll(mask);
-                if (lane + XC_WAVE * c < r && in_new[c] != (cur.sel[c] != 0))
+                if (lane + XC_WAVE * c < r && in_new[c] != (cur.sel[c] != 0)) {
                     P.sel[s0 + lane + XC_WAVE * c] = in_new[c] ? 1 : 0;
+                    if (PACKED)
+                        reinterpret_cast<unsigned *>(P.packed + s0 + lane + XC_WAVE * c)[0] =
+                            (unsigned)cur.idx[c] | (in_new[c] ? 0x80000000u : 0u);
+                }
                 if (lane + XC_WAVE * c < r) {
                     double *st = P.tpfp + (int64_t)cur.idx[c] * 2;
                     const double ed = (double)cur.eta[c];
@@ -541,6 +558,21 @@ __global__ __launch_bounds__(XC_BLOCK) void expand_colsum_kernel(int64_t nnz, co
     const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride)
         s_entry[t] = colsum[indices[t]];
+}
+
+// packed[p] = {col | sel << 31, eta, s}: the four row streams of a float32 matrix interleaved
+__global__ __launch_bounds__(XC_BLOCK) void pack_rows_kernel(int64_t nnz, const int32_t *indices, const float *data,
+                                                             const uint8_t *sel, const double *s_entry, uint4_t *packed) {
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride) {
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(s_entry[t]);
+        uint4_t w;
+        w.x = (unsigned)indices[t] | (sel[t] ? 0x80000000u : 0u);
+        w.y = __float_as_uint(data[t]);
+        w.z = (unsigned)sb;
+        w.w = (unsigned)(sb >> 32);
+        packed[t] = w;
+    }
 }
 
 // ---- tp / fp of the current prediction from scratch ------------------------------
@@ -641,47 +673,58 @@ static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stam
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_validate = 1;                           // xc_bca_set_validation
 
-template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW>
+template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED>
 static void launch_sweep_one(const SweepParams<T> &P, hipStream_t st) {
     const int blocks = (P.n_waves + 3) / 4;
     if (g_ev_start && g_ev_stop) {
         // start / stop events attached to the dispatch itself: the measured span is the
         // kernel, not the kernel plus the dispatch gap an event pair around it would add
-        hipExtLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st,
-                              g_ev_start, g_ev_stop, 0, P);
+        hipExtLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED>), dim3(blocks),
+                              dim3(XC_BLOCK), 0, st, g_ev_start, g_ev_stop, 0, P);
         g_ev_start = g_ev_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW>), dim3(blocks), dim3(XC_BLOCK), 0, st, P);
+        hipLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED>), dim3(blocks), dim3(XC_BLOCK),
+                           0, st, P);
     }
 }
 
-template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW>
+template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED>
 static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
     switch (ch) {
-    case 1: launch_sweep_one<T, 1, EXACT, HAS_ORDER, SHADOW>(P, st); break;
-    case 2: launch_sweep_one<T, 2, EXACT, HAS_ORDER, SHADOW>(P, st); break;
-    case 4: launch_sweep_one<T, 4, EXACT, HAS_ORDER, SHADOW>(P, st); break;
-    case 8: launch_sweep_one<T, 8, EXACT, HAS_ORDER, SHADOW>(P, st); break;
-    default: launch_sweep_one<T, 16, EXACT, HAS_ORDER, SHADOW>(P, st); break;
+    case 1: launch_sweep_one<T, 1, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
+    case 2: launch_sweep_one<T, 2, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
+    case 4: launch_sweep_one<T, 4, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
+    case 8: launch_sweep_one<T, 8, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
+    default: launch_sweep_one<T, 16, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
+    }
+}
+
+template <typename T, bool PACKED>
+static void launch_sweep_mode(const SweepParams<T> &P, int ch, hipStream_t st) {
+    const bool exact = P.n_waves == 1;
+    const bool shadow = !exact && !P.greedy && P.shadow != nullptr;
+    if (P.order) {
+        if (exact) launch_sweep_impl<T, true, true, false, PACKED>(P, ch, st);
+        else if (shadow) launch_sweep_impl<T, false, true, true, PACKED>(P, ch, st);
+        else launch_sweep_impl<T, false, true, false, PACKED>(P, ch, st);
+    } else {
+        if (exact) launch_sweep_impl<T, true, false, false, PACKED>(P, ch, st);
+        else if (shadow) launch_sweep_impl<T, false, false, true, PACKED>(P, ch, st);
+        else launch_sweep_impl<T, false, false, false, PACKED>(P, ch, st);
     }
 }
 
 // n_waves == 1 is the sequential mode that must reproduce the reference's
 // trajectory: it keeps the reference's divisions and reads the float64 records.
-// The float32 shadow is read by the concurrent, non-greedy sweep only.
-template <typename T>
-static void launch_sweep(const SweepParams<T> &P, int ch, hipStream_t st) {
-    const bool exact = P.n_waves == 1;
-    const bool shadow = !exact && !P.greedy && P.shadow != nullptr;
-    if (P.order) {
-        if (exact) launch_sweep_impl<T, true, true, false>(P, ch, st);
-        else if (shadow) launch_sweep_impl<T, false, true, true>(P, ch, st);
-        else launch_sweep_impl<T, false, true, false>(P, ch, st);
-    } else {
-        if (exact) launch_sweep_impl<T, true, false, false>(P, ch, st);
-        else if (shadow) launch_sweep_impl<T, false, false, true>(P, ch, st);
-        else launch_sweep_impl<T, false, false, false>(P, ch, st);
-    }
+// The float32 shadow is read by the concurrent, non-greedy sweep only; the packed row
+// stream exists for float32 scores and non-greedy sweeps.
+static void launch_sweep(const SweepParams<float> &P, int ch, hipStream_t st) {
+    if (P.packed && !P.greedy) launch_sweep_mode<float, true>(P, ch, st);
+    else launch_sweep_mode<float, false>(P, ch, st);
+}
+
+static void launch_sweep(const SweepParams<double> &P, int ch, hipStream_t st) {
+    launch_sweep_mode<double, false>(P, ch, st);
 }
 
 static int grid_for(int64_t n_items) {
@@ -740,6 +783,17 @@ int xc_bca_expand_colsum(int64_t nnz, const int32_t *indices, const double *cols
     hipLaunchKernelGGL(xc::expand_colsum_kernel, dim3(xc::grid_for(nnz)), dim3(XC_BLOCK), 0, xc::as_stream(stream), nnz,
                        indices, colsum, s_entry);
     XC_CHECK_LAUNCH("expand_colsum_kernel");
+    return XC_OK;
+}
+
+int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data, const uint8_t *sel,
+                     const double *s_entry, void *packed, void *stream) {
+    if (nnz < 0 || (nnz > 0 && (!indices || !data || !sel || !s_entry || !packed)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_pack_rows: bad argument");
+    if (nnz == 0) return XC_OK;
+    hipLaunchKernelGGL(xc::pack_rows_kernel, dim3(xc::grid_for(nnz)), dim3(XC_BLOCK), 0, xc::as_stream(stream), nnz, indices,
+                       data, sel, s_entry, static_cast<xc::uint4_t *>(packed));
+    XC_CHECK_LAUNCH("pack_rows_kernel");
     return XC_OK;
 }
 
@@ -805,8 +859,8 @@ int xc_utility_finish_host(const double *partials, double *out_host, double *out
 int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz,
                      int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, double *acc,
-                     const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
+                     int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
+                     double *acc, const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
                      int64_t *changed, void *stream) {
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
         !metric_host)
@@ -831,18 +885,18 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
     fast.kf *= (double)n_norm;
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
-                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry, acc, m,
-                                 (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                 static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
+                                 static_cast<xc::uint4_t *>(packed), acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
-        xc::launch_sweep<float>(P, ch, st);
+        xc::launch_sweep(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
-                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry, acc, m,
-                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                  static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
+                                  nullptr, acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                   (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
-        xc::launch_sweep<double>(P, ch, st);
+        xc::launch_sweep(P, ch, st);
     }
     XC_CHECK_LAUNCH("bca_sweep_csr_kernel");
     return XC_OK;
@@ -900,6 +954,7 @@ struct xc_bca_plan_s {
     float *shadow;
     double *colsum;
     const double *s_entry;
+    void *packed;
     double *acc, *partials;
     xc_metric gain_metric, utility_metric;
     int maximize, skip_tn;
@@ -908,11 +963,11 @@ struct xc_bca_plan_s {
 int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total, const int32_t *indptr,
                        const int32_t *indices, const void *data, int dtype, int max_row_nnz, int k,
                        int32_t *pred_indices, void *pred_eta, uint8_t *sel, double *tpfp, float *shadow,
-                       double *colsum, const double *s_entry, double *acc, double *partials,
+                       double *colsum, const double *s_entry, void *packed, double *acc, double *partials,
                        const xc_metric *gain_metric, const xc_metric *utility_metric, int maximize, int skip_tn) {
     if (!plan || !gain_metric || !utility_metric) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_create: NULL pointer");
     xc_bca_plan_s *p = new xc_bca_plan_s{n, m, n_total, indptr, indices, data, dtype, max_row_nnz, k, pred_indices,
-                                         pred_eta, sel, tpfp, shadow, colsum, s_entry, acc, partials, *gain_metric,
+                                         pred_eta, sel, tpfp, shadow, colsum, s_entry, packed, acc, partials, *gain_metric,
                                          *utility_metric, maximize, skip_tn};
     *plan = p;
     return XC_OK;
@@ -924,12 +979,12 @@ int xc_bca_plan_destroy(void *plan) {
 }
 
 int xc_bca_plan_sweep(void *plan, const int32_t *order, int64_t n_order, const int32_t *orphans, int greedy,
-                      int n_waves, int with_acc, int64_t *changed, void *stream) {
+                      int n_waves, int with_acc, int use_packed, int64_t *changed, void *stream) {
     if (!plan) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep: NULL plan");
     const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
     return xc_bca_sweep_csr(n_order, order, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
                             p->pred_indices, p->pred_eta, p->sel, orphans, p->k, p->m, p->tpfp, p->shadow, p->colsum,
-                            p->s_entry, with_acc ? p->acc : nullptr, &p->gain_metric, p->maximize, greedy, p->skip_tn,
+                            p->s_entry, use_packed ? p->packed : nullptr, with_acc ? p->acc : nullptr, &p->gain_metric, p->maximize, greedy, p->skip_tn,
                             n_waves, changed, stream);
 }
 
