@@ -108,3 +108,53 @@ def product_call_from_spec(spec, y_proba, init_matrix=None, **extra):
         return bc.predict_using_bc_with_0approx(y_proba, getattr(pm, spec["metric"]), spec["k"],
                                                 return_meta=True, **kw)
     return getattr(bc, spec["entry"])(y_proba, spec["k"], return_meta=True, **kw)
+
+
+# ---------------------------------------------------------------------------
+# Frank-Wolfe fixtures (tests/golden/fw.npz)
+# ---------------------------------------------------------------------------
+# wrapper -> (stem, average, skip_tn)   frank_wolfe.py:743-815
+FW_STEMS = {"precision": "PRECISION", "recall": "RECALL", "f1_score": "FBETA", "fbeta_score": "FBETA",
+            "jaccard_score": "JACCARD", "balanced_accuracy": "BALANCED_ACC", "hmean": "HMEAN", "gmean": "GMEAN"}
+FW_SKIP_TN = {"precision": True, "recall": True, "f1_score": True, "jaccard_score": True,
+              "balanced_accuracy": False, "hmean": False, "gmean": False}
+
+
+def fw_cases(z):
+    return [json.loads(str(s)) for s in z["specs"]]
+
+
+def fw_inputs(z, spec):
+    tag = spec["dtype"]
+    mats = [csr_from(z, f"{p}_{tag}") for p in ("true", "proba", "test")]
+    if spec["layout"] == "dense":
+        mats = [x.toarray() for x in mats]
+    return mats
+
+
+def fw_oracle_call(fw, z, spec):
+    """Run the oracle's Frank-Wolfe the way the reference entry point named in `spec` would."""
+    y_true, y_proba, _ = fw_inputs(z, spec)
+    kw = dict(spec["kwargs"])
+    k = spec["k"]
+    m = y_proba.shape[1]
+    entry = spec["entry"]
+    mkw = kw.pop("metric_kwargs", None) or {}
+    if entry.startswith("generic:"):
+        avg, stem = entry.split(":")[1].replace("_on_conf_matrix", "").split("_", 1)
+        metric = fw.FwMetric(base=getattr(fw, FW_STEMS[stem]), average=avg, **{kk: vv for kk, vv in mkw.items()})
+        kw.setdefault("skip_tn", False)
+    elif "mixed" in entry:
+        alpha = kw.pop("alpha", 1)
+        if "recall_and_macro_precision" in entry:
+            metric = fw.FwMetric(base=fw.RECALL_PRECISION_MIX, average="sum", alpha=alpha)
+        else:
+            stem = entry.split("_and_macro_")[1].replace("_using_fw", "")
+            metric = fw.FwMetric(base=getattr(fw, FW_STEMS[stem]), average="sum", mixed=True, alpha=alpha, k=k, m=m)
+    else:
+        avg, stem = entry.replace("find_classifier_optimizing_", "").replace("_using_fw", "").split("_", 1)
+        metric = fw.FwMetric(base=getattr(fw, FW_STEMS[stem]), average=avg)
+        kw["skip_tn"] = FW_SKIP_TN[stem]
+    if spec["init_ab"]:
+        kw["init_classifier"] = (z["init_a"], z["init_b"])
+    return fw.find_classifier_using_fw(y_true, y_proba, metric, k, **kw)

@@ -423,7 +423,127 @@ def gen_eval():
     save("eval_f64", **out)
 
 
+# ---------------------------------------------------------------------------
+# G. Frank-Wolfe (frank_wolfe.py:407-690) and the randomized classifier (:85-172)
+# ---------------------------------------------------------------------------
+# frank_wolfe.py imports the `autograd` package (:4-5), absent from this image, for ONE
+# call: autograd.grad(metric_func, argnum=[0, 1, 2, 3]) (:368-376).  The stand-in below
+# differentiates the reference's own metric functions with torch.autograd on CPU tensors
+# of the arrays' own dtype -- what the reference's torch branch does (:18-41) -- and hands
+# numpy itself out as `autograd.numpy`.  Everything else that runs is the reference's code.
+
+def _install_autograd_standin():
+    import torch
+
+    mod = types.ModuleType("autograd")
+
+    def grad(func, argnum):
+        def gradient(*args):
+            ts = [torch.tensor(np.asarray(x), requires_grad=True) for x in args]
+            value = func(*ts)
+            gs = torch.autograd.grad(value, [ts[i] for i in argnum], allow_unused=True, materialize_grads=True)
+            return tuple(g.numpy() for g in gs)
+        return gradient
+
+    mod.grad = grad
+    mod.numpy = np
+    sys.modules["autograd"] = mod
+    sys.modules["autograd.numpy"] = np
+
+
+FW_CASES = [
+    # name, entry (wrapper name or "generic:<metric>"), layout, dtype, k, kwargs
+    ("macro_recall_init", "generic:macro_recall_on_conf_matrix", "csr", "f32", 3, dict(seed=2024, init="ab")),
+    ("macro_f1_top", "find_classifier_optimizing_macro_f1_score_using_fw", "csr", "f32", 3, dict(max_iters=10)),
+    ("micro_f1", "find_classifier_optimizing_micro_f1_score_using_fw", "csr", "f64", 3,
+     dict(max_iters=6, init_classifier="random", seed=11)),
+    ("macro_precision_dense", "find_classifier_optimizing_macro_precision_using_fw", "dense", "f32", 3, dict(max_iters=8)),
+    ("macro_jaccard_random", "find_classifier_optimizing_macro_jaccard_score_using_fw", "csr", "f32", 4,
+     dict(init_classifier="random", seed=7, max_iters=8)),
+    ("macro_balanced_accuracy_dense", "find_classifier_optimizing_macro_balanced_accuracy_using_fw", "dense", "f64", 3,
+     dict(max_iters=6)),
+    ("macro_hmean", "find_classifier_optimizing_macro_hmean_using_fw", "csr", "f32", 3, dict(max_iters=6)),
+    ("macro_gmean", "find_classifier_optimizing_macro_gmean_using_fw", "csr", "f64", 3, dict(max_iters=6)),
+    ("micro_jaccard_dense", "find_classifier_optimizing_micro_jaccard_score_using_fw", "dense", "f32", 2,
+     dict(max_iters=5, init_classifier="random", seed=5)),
+    ("mixed_precision_f1", "find_classifier_optimizing_mixed_instance_precision_and_macro_f1_score_using_fw", "csr",
+     "f32", 3, dict(alpha=0.5, max_iters=8)),
+    ("mixed_recall_precision", "find_classifier_optimizing_mixed_macro_recall_and_macro_precision_using_fw", "csr",
+     "f32", 3, dict(alpha=0.3, max_iters=8)),
+    ("macro_f1_ternary", "find_classifier_optimizing_macro_f1_score_using_fw", "csr", "f32", 3,
+     dict(alpha_search_algo="ternary", max_iters=8, init_classifier="random", seed=3)),
+    ("macro_f1_fixed_step", "find_classifier_optimizing_macro_f1_score_using_fw", "csr", "f32", 3,
+     dict(search_for_best_alpha=False, max_iters=6, init_classifier="random", seed=4, tolerance=-1.0)),
+    ("macro_f1_prior_init", "find_classifier_optimizing_macro_f1_score_using_fw", "csr", "f32", 3,
+     dict(init_classifier="prior", max_iters=6)),
+    ("macro_f1_k0", "find_classifier_optimizing_macro_f1_score_using_fw", "csr", "f32", 0, dict(max_iters=6)),
+    ("macro_recall_unnormalized", "generic:macro_recall_on_conf_matrix", "csr", "f32", 3,
+     dict(normalize_conf_matrix=False, max_iters=6, skip_tn=True)),
+    ("macro_f1_beta_kwargs", "generic:macro_fbeta_score_on_conf_matrix", "csr", "f32", 3,
+     dict(metric_kwargs={"beta": 2.0, "epsilon": 1e-6}, max_iters=6, skip_tn=True)),
+]
+
+
+def gen_fw():
+    _install_autograd_standin()
+    import xcolumns.frank_wolfe as ref_fw
+
+    rng = np.random.default_rng(701)
+    n, m, r = 700, 90, 12
+    out = {}
+    mats = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        Yp = fixed_csr(rng, n, m, r, dt, skew=False)
+        Yp.data = (Yp.data.astype(np.float64) ** 2).astype(dt)
+        Yt = Yp.copy()
+        Yt.data = (rng.random(Yp.nnz) < Yp.data).astype(dt)
+        Yt.eliminate_zeros()
+        Yt.sort_indices()
+        Ytest = fixed_csr(rng, 300, m, r, dt)
+        mats[tag] = (Yt, Yp, Ytest)
+        out.update(csr_fields(f"true_{tag}", Yt))
+        out.update(csr_fields(f"proba_{tag}", Yp))
+        out.update(csr_fields(f"test_{tag}", Ytest))
+    init_a = rng.random(m)
+    init_b = rng.random(m)
+    out["init_a"], out["init_b"] = init_a, init_b
+    specs = []
+    for ci, (name, entry, layout, tag, k, kw) in enumerate(FW_CASES):
+        Yt, Yp, Ytest = mats[tag]
+        if layout == "dense":
+            Yt, Yp, Ytest = Yt.toarray(), Yp.toarray(), Ytest.toarray()
+        kw = dict(kw)
+        if kw.pop("init", None) == "ab":
+            kw["init_classifier"] = (init_a, init_b)
+        if entry.startswith("generic:"):
+            metric = getattr(ref_metrics, entry.split(":")[1])
+            clf, meta = ref_fw.find_classifier_using_fw(Yt, Yp, metric, k, return_meta=True, **kw)
+        else:
+            clf, meta = getattr(ref_fw, entry)(Yt, Yp, k, return_meta=True, **kw)
+        assert np.isfinite(clf.a).all() and np.isfinite(clf.b).all(), name
+        pred = clf.predict(Ytest, seed=2024)
+        pred_csr = pred if isinstance(pred, csr_matrix) else csr_matrix(pred)
+        pred_csr.sort_indices()
+        assert clf.a.dtype == np.float32 and clf.p.dtype == np.float32
+        out[f"c{ci}_a"], out[f"c{ci}_b"], out[f"c{ci}_p"] = clf.a, clf.b, clf.p
+        out[f"c{ci}_alphas"] = np.asarray(meta["alphas"], dtype=np.float64)
+        out[f"c{ci}_utilities"] = np.asarray(meta["utilities"], dtype=np.float64)
+        out[f"c{ci}_classifiers_utilities"] = np.asarray(meta["classifiers_utilities"], dtype=np.float64)
+        out[f"c{ci}_iters"] = np.int64(meta["iters"])
+        out[f"c{ci}_pred_indices"] = pred_csr.indices
+        out[f"c{ci}_pred_indptr"] = pred_csr.indptr
+        out[f"c{ci}_pred_dtype"] = np.asarray(str(pred.dtype))
+        kw_json = {k_: v for k_, v in kw.items() if k_ != "init_classifier" or isinstance(v, str)}
+        specs.append(json.dumps(dict(name=name, entry=entry, layout=layout, dtype=tag, k=k, kwargs=kw_json,
+                                     init_ab="init_classifier" in kw and not isinstance(kw["init_classifier"], str)),
+                                sort_keys=True))
+        print(f"  fw case {ci} {name}: iters {meta['iters']}, classifiers {clf.a.shape[0]}, "
+              f"utility {meta['utilities'][0]:.6f} -> {meta['utilities'][-1]:.6f}, alphas {meta['alphas'][:3]}")
+    out["specs"] = np.asarray(specs)
+    save("fw", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval"]
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw"]
     for w in which:
         globals()["gen_" + w]()

@@ -113,3 +113,35 @@ def test_bca_dense_golden(oref, tag):
             name, meta["utilities"], z["utilities_" + name])
         assert P.dtype == Y.dtype
         assert np.array_equal(P, z["pred_" + name]), name
+
+
+def test_frank_wolfe_golden():
+    """oracle/fw_ref.py against the reference's find_classifier_using_fw + RandomizedWeightedClassifier.predict.
+    The reference differentiates with autograd, the oracle with closed forms: the float32 classifier
+    tables may differ in the last bit, everything discrete (iterations, alphas, predictions) must match."""
+    from oracle import fw_ref as fw
+
+    z = G.load("fw")
+    for ci, spec in enumerate(G.fw_cases(z)):
+        A, B, P, meta = G.fw_oracle_call(fw, z, spec)
+        name = spec["name"]
+        assert meta["iters"] == int(z[f"c{ci}_iters"]), name
+        assert A.shape == z[f"c{ci}_a"].shape and A.dtype == np.float32, name
+        # a few float32 ulps: for float32 inputs the first gradient is float32 arithmetic on both sides
+        scale = float(np.abs(z[f"c{ci}_a"]).max())
+        np.testing.assert_allclose(A, z[f"c{ci}_a"], rtol=5e-6, atol=5e-7 * scale, err_msg=name)
+        np.testing.assert_allclose(B, z[f"c{ci}_b"], rtol=5e-6, atol=5e-7 * scale, err_msg=name)
+        np.testing.assert_array_equal(P, z[f"c{ci}_p"], err_msg=name)
+        np.testing.assert_array_equal(np.asarray(meta["alphas"]), z[f"c{ci}_alphas"], err_msg=name)
+        np.testing.assert_allclose(meta["utilities"], z[f"c{ci}_utilities"], rtol=1e-13, err_msg=name)
+        np.testing.assert_allclose(meta["classifiers_utilities"], z[f"c{ci}_classifiers_utilities"], rtol=1e-13,
+                                   err_msg=name)
+        # the randomized classifier, with the REFERENCE's tables so the check is independent of the above
+        _, _, y_test = G.fw_inputs(z, spec)
+        pred = fw.predict_using_randomized_weighted_classifier(y_test, spec["k"], z[f"c{ci}_a"], z[f"c{ci}_b"],
+                                                               z[f"c{ci}_p"], seed=2024)
+        assert str(pred.dtype) == str(z[f"c{ci}_pred_dtype"]), name
+        pc = pred if isinstance(pred, csr_matrix) else csr_matrix(pred)
+        pc.sort_indices()
+        np.testing.assert_array_equal(pc.indptr, z[f"c{ci}_pred_indptr"], err_msg=name)
+        np.testing.assert_array_equal(pc.indices, z[f"c{ci}_pred_indices"], err_msg=name)
