@@ -57,7 +57,8 @@ enum {
     XC_M_GMEAN = 6,          /* metrics.py:873-894 */
     XC_M_HMEAN = 7,          /* metrics.py:922-944 */
     XC_M_ACCURACY = 8,       /* metrics.py:400-419 */
-    XC_M_COUNT = 9
+    XC_M_RECALL_PRECISION_MIX = 9, /* (1 - alpha) * recall + alpha * precision, frank_wolfe.py:925-929 */
+    XC_M_COUNT = 10
 };
 
 typedef struct xc_metric {
@@ -309,6 +310,51 @@ int xc_bca_sweep_dense(int64_t n_order, const int32_t *order, int64_t n_norm,
 /* Utility of four plain vectors (dense path): partials as above. */
 int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
                        const xc_metric *metric_host, double *partials, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Frank-Wolfe search for a randomized weighted classifier
+ * (xcolumns/frank_wolfe.py:407-690).  An iteration is
+ * xc_topk_csr with weights (a, b) -> xc_confusion_csr against y_true -> the two
+ * O(m) steps below.  stats / cur / nxt: float64[4*m] as tp | fp | fn | tn.
+ * ------------------------------------------------------------------------- */
+
+/* Gradient of the utility in the confusion entries, folded into the next weighted
+ * classifier (frank_wolfe.py:585-596; replaces autograd.grad, :368-376):
+ *   G_x[j] = d metric(tp_j, fp_j, fn_j, tn_j) / d x / div      (div = m for a macro
+ *            average -- the mean's 1/m --, 1 for a sum)
+ *   a[j] = G_tp - G_fp - G_fn + G_tn,  b[j] = G_fp - G_tn,  both negated if `negate`
+ * (minimisation, :594-596).  For a micro average pass the four label sums as an
+ * m = 1 problem and broadcast the result. */
+int xc_fw_gradient(int64_t m, const double *stats, const xc_metric *metric_host, double div,
+                   int negate, double *a, double *b, void *stream);
+
+/* Utility along the segment between two confusion matrices (frank_wolfe.py:379-404,
+ * _find_best_alpha): for every alphas[t]
+ *   sum_j metric((1 - alpha) * cur_j + alpha * nxt_j)
+ * left as partial sums partials[c * n_alpha + t], c < xc_fw_alpha_chunks(m), to be
+ * added over c in ascending order.  The caller picks the step (first maximum for the
+ * uniform search, utils.py:174-184; two points per step for the ternary one,
+ * :187-201). */
+int xc_fw_alpha_chunks(int64_t m);
+int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt,
+                      const xc_metric *metric_host, int n_alpha, const double *alphas,
+                      double *partials, void *stream);
+
+/* xc_topk_csr / xc_threshold_*_csr with one weighted classifier PER ROW
+ * (predict_using_randomized_weighted_classifier, frank_wolfe.py:127-172): row i
+ * uses a[row_classifier[i] * ld + col], b[...] (tables of y_proba's dtype). */
+int xc_topk_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices,
+                        const void *data, int dtype, int max_row_nnz, int k, const void *a,
+                        const void *b, int64_t ld, const int32_t *row_classifier,
+                        int32_t *out_indices, void *stream);
+int xc_threshold_count_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices,
+                                   const void *data, int dtype, double th, const void *a,
+                                   const void *b, int64_t ld, const int32_t *row_classifier,
+                                   int32_t *out_counts, void *stream);
+int xc_threshold_fill_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices,
+                                  const void *data, int dtype, double th, const void *a,
+                                  const void *b, int64_t ld, const int32_t *row_classifier,
+                                  const int32_t *out_indptr, int32_t *out_indices, void *stream);
 
 #ifdef __cplusplus
 }

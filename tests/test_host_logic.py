@@ -141,3 +141,37 @@ def test_shard_helpers():
     assert sorted(got.tolist()) == list(range(n))
     lo, hi = bounds[1]
     assert np.array_equal(local_order(order, lo, hi) + lo, order[(order >= lo) & (order < hi)])
+
+
+def test_draw_classifiers_matches_sequential_choice():
+    """The vectorised per-row classifier draw equals n sequential rng.choice(range(c), p=p) calls
+    (frank_wolfe.py:99, :153); probabilities are validated like numpy's Generator.choice does."""
+    from oracle import fw_ref
+    from xcolumns_amd.frank_wolfe import draw_classifiers
+
+    rng = np.random.default_rng(0)
+    for p in (np.array([0.2, 0.5, 0.3], dtype=np.float32), np.array([1.0], dtype=np.float32),
+              rng.dirichlet(np.ones(9)).astype(np.float32), rng.dirichlet(np.ones(4))):
+        assert np.array_equal(draw_classifiers(3000, p, 2024), fw_ref.draw_classifiers(3000, p, 2024))
+    with pytest.raises(ValueError):
+        draw_classifiers(10, np.array([0.4, 0.4]), 1)
+    with pytest.raises(ValueError):
+        draw_classifiers(10, np.array([1.5, -0.5]), 1)
+
+
+def test_fw_metric_resolution():
+    import xcolumns_amd.frank_wolfe as xfw
+    import xcolumns_amd.metrics as xm
+    from xcolumns_amd import _lib
+
+    o = xfw.resolve_fw_metric(xm.macro_fbeta_score_on_conf_matrix, {"beta": 2.0, "epsilon": 1e-6})
+    assert o.average == "macro" and o.spec.base == _lib.XC_M_FBETA and o.spec.beta == 2.0 and o.spec.epsilon == 1e-6
+    assert xfw.resolve_fw_metric(xm.micro_hmean_on_conf_matrix).average == "micro"
+    with pytest.raises(NotImplementedError):
+        xfw.resolve_fw_metric(lambda tp, fp, fn, tn: tp.sum())
+    with pytest.raises(ValueError):
+        xfw.resolve_fw_metric(xm.macro_recall_on_conf_matrix, {"beta": 2.0})
+    # the wrappers keep the reference's introspectable signature (frank_wolfe.py:743-747)
+    import inspect
+    sig = inspect.signature(xfw.find_classifier_optimizing_macro_f1_score_using_fw)
+    assert "max_iters" in sig.parameters and "metric_func" not in sig.parameters and "skip_tn" not in sig.parameters

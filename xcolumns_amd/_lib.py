@@ -24,7 +24,7 @@ XC_ERR_BAD_ARG, XC_ERR_K_RANGE, XC_ERR_ROW_TOO_LONG, XC_ERR_NO_DEVICE = -1, -2, 
 
 # metric ids (include/xcolumns_amd.h)
 (XC_M_PRECISION_AT_K, XC_M_PRECISION, XC_M_RECALL, XC_M_FBETA, XC_M_JACCARD,
- XC_M_BALANCED_ACC, XC_M_GMEAN, XC_M_HMEAN, XC_M_ACCURACY) = range(9)
+ XC_M_BALANCED_ACC, XC_M_GMEAN, XC_M_HMEAN, XC_M_ACCURACY, XC_M_RECALL_PRECISION_MIX) = range(10)
 
 
 class XcMetric(ctypes.Structure):
@@ -62,6 +62,15 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_colsum_csr": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_expand_colsum": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xc_fw_gradient": (c_int, [c_int64, c_void_p, POINTER(XcMetric), c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "xc_fw_alpha_chunks": (c_int, [c_int64]),
+    "xc_fw_alpha_curve": (c_int, [c_int64, c_void_p, c_void_p, POINTER(XcMetric), c_int, c_void_p, c_void_p, c_void_p]),
+    "xc_topk_csr_rowwise": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_int64, c_void_p, c_void_p, c_void_p]),
+    "xc_threshold_count_csr_rowwise": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p,
+                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "xc_threshold_fill_csr_rowwise": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p,
+                                              c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_pack_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_accumulate_pred": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_commit_utility": (c_int, [c_int64, c_int64, c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

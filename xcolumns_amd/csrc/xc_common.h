@@ -183,6 +183,8 @@ __device__ __forceinline__ double metric_base_t(const xc_metric &mt, double tp, 
     }
     case XC_M_ACCURACY: // :416-419
         return fdiv<EXACT>(tp + tn, tp + fp + fn + tn);
+    case XC_M_RECALL_PRECISION_MIX: // frank_wolfe.py:925-929
+        return (1.0 - mt.alpha) * fdiv<EXACT>(tp, tp + fn + eps) + mt.alpha * fdiv<EXACT>(tp, tp + fp + eps);
     default:
         return __builtin_nan("");
     }

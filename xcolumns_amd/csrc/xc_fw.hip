@@ -1,0 +1,186 @@
+// xc_fw.hip -- the O(m) side of the Frank-Wolfe search (xcolumns/frank_wolfe.py:407-690):
+// the gradient of the utility in the 4 x m confusion entries (:368-376, :585-596) and
+// the utility along the segment between two confusion matrices (:379-404).
+//
+// The reference differentiates its numpy metric formulas with the `autograd` package;
+// here the same formulas (metrics.py:497-944, written once as fw_metric<N>) are
+// instantiated on forward-mode dual numbers carrying the four partial derivatives,
+// so value and gradient come from one evaluation per label.
+//
+// Both kernels are float64 VALU work on vectors that fit in L2 / MALL (32 B per label):
+// the gradient is one pass; the step-size search evaluates the metric m x n_alpha times
+// (n_alpha = 10^4 for the default uniform search), tiled so that a workgroup stages 256
+// labels in LDS and every thread owns one alpha.
+#include "xc_common.h"
+#include "xc_host.h"
+
+#define XC_FW_TILE 256
+
+namespace xc {
+
+struct Dual {
+    double v, d0, d1, d2, d3;
+    __device__ Dual() {}
+    __device__ Dual(double x) : v(x), d0(0.0), d1(0.0), d2(0.0), d3(0.0) {}
+    __device__ Dual(double x, double a, double b, double c, double d) : v(x), d0(a), d1(b), d2(c), d3(d) {}
+};
+
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d0 + b.d0, a.d1 + b.d1, a.d2 + b.d2, a.d3 + b.d3); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d0 - b.d0, a.d1 - b.d1, a.d2 - b.d2, a.d3 - b.d3); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) {
+    return Dual(a.v * b.v, a.d0 * b.v + a.v * b.d0, a.d1 * b.v + a.v * b.d1, a.d2 * b.v + a.v * b.d2,
+                a.d3 * b.v + a.v * b.d3);
+}
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+    const double q = a.v / b.v;
+    return Dual(q, (a.d0 - q * b.d0) / b.v, (a.d1 - q * b.d1) / b.v, (a.d2 - q * b.d2) / b.v, (a.d3 - q * b.d3) / b.v);
+}
+__device__ __forceinline__ Dual nsqrt(Dual a) {
+    const double s = sqrt(a.v);
+    const double h = 0.5 / s;
+    return Dual(s, h * a.d0, h * a.d1, h * a.d2, h * a.d3);
+}
+__device__ __forceinline__ double nsqrt(double a) { return sqrt(a); }
+
+// metrics.py formulas in the reference's operation order (the file is compiled with
+// -ffp-contract=off), for N = double or Dual
+template <typename N>
+__device__ __forceinline__ N fw_base(const xc_metric &mt, N tp, N fp, N fn, N tn) {
+    const double eps = mt.epsilon;
+    switch (mt.base) {
+    case XC_M_PRECISION_AT_K: return tp / N(mt.kf);                       // :513
+    case XC_M_PRECISION: return tp / (tp + fp + N(eps));                   // :605
+    case XC_M_RECALL: return tp / (tp + fn + N(eps));                      // :652
+    case XC_M_FBETA: {                                                     // :703
+        const double b2 = mt.beta * mt.beta;
+        return (N(1.0 + b2) * tp) / ((N(b2) * (tp + fp)) + tp + fn + N(eps));
+    }
+    case XC_M_JACCARD: return tp / (tp + fp + fn + N(eps));                // :797
+    case XC_M_BALANCED_ACC: {                                              // :843-845
+        const N tpr = tp / (tp + fn + N(eps));
+        const N tnr = tn / (tn + fp + N(eps));
+        return (tpr + tnr) / N(2.0);
+    }
+    case XC_M_GMEAN: {                                                     // :892-894
+        const N tpr = tp / (tp + fn + N(eps));
+        const N tnr = tn / (tn + fp + N(eps));
+        return nsqrt(tpr * tnr);
+    }
+    case XC_M_HMEAN: {                                                     // :942-944
+        const N tpr = tp / (tp + fn + N(eps));
+        const N tnr = tn / (tn + fp + N(eps));
+        return (N(2.0) * tpr * tnr) / (tpr + tnr);
+    }
+    case XC_M_ACCURACY: return (tp + tn) / (tp + fp + fn + tn);            // :416-419
+    case XC_M_RECALL_PRECISION_MIX:                                        // frank_wolfe.py:925-929
+        return N(1.0 - mt.alpha) * (tp / (tp + fn + N(eps))) + N(mt.alpha) * (tp / (tp + fp + N(eps)));
+    default: return N(__builtin_nan(""));
+    }
+}
+
+template <typename N>
+__device__ __forceinline__ N fw_metric(const xc_metric &mt, N tp, N fp, N fn, N tn) {
+    N v = fw_base<N>(mt, tp, fp, fn, tn);
+    if (mt.mixed) // frank_wolfe.py:832-838
+        v = N(1.0 - mt.alpha) * (tp / N(mt.kf)) + (N(mt.alpha) * v) / N(mt.mf);
+    return v;
+}
+
+// a_j = G_tp - G_fp - G_fn + G_tn, b_j = G_fp - G_tn (frank_wolfe.py:592-593); G = dpsi_j / d(.) / div
+__global__ __launch_bounds__(XC_BLOCK) void fw_gradient_kernel(int64_t m, const double *stats, xc_metric metric,
+                                                               double div, int negate, double *a, double *b) {
+    const int64_t j = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const Dual tp(stats[j], 1.0, 0.0, 0.0, 0.0), fp(stats[m + j], 0.0, 1.0, 0.0, 0.0);
+    const Dual fn(stats[2 * m + j], 0.0, 0.0, 1.0, 0.0), tn(stats[3 * m + j], 0.0, 0.0, 0.0, 1.0);
+    const Dual u = fw_metric<Dual>(metric, tp, fp, fn, tn);
+    const double gtp = u.d0 / div, gfp = u.d1 / div, gfn = u.d2 / div, gtn = u.d3 / div;
+    double aj = gtp - gfp - gfn + gtn;
+    double bj = gfp - gtn;
+    if (negate) { // :594-596
+        aj = -aj;
+        bj = -bj;
+    }
+    a[j] = aj;
+    b[j] = bj;
+}
+
+// partials[chunk][t] = sum over the chunk's labels of psi((1 - alpha_t) * cur_j + alpha_t * nxt_j)
+__global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, const double *cur, const double *nxt,
+                                                                   xc_metric metric, int n_alpha,
+                                                                   const double *alphas, int64_t per_chunk,
+                                                                   double *partials) {
+    __shared__ double s_cur[4][XC_FW_TILE];
+    __shared__ double s_nxt[4][XC_FW_TILE];
+    const int t = blockIdx.x * XC_FW_TILE + threadIdx.x;
+    const bool live = t < n_alpha;
+    const double alpha = live ? alphas[t] : 0.0;
+    const double keep = 1.0 - alpha;
+    const int64_t j0 = (int64_t)blockIdx.y * per_chunk;
+    const int64_t j1 = (j0 + per_chunk < m) ? j0 + per_chunk : m;
+    double sum = 0.0;
+    for (int64_t base = j0; base < j1; base += XC_FW_TILE) {
+        const int64_t j = base + threadIdx.x;
+        const int cnt = (int)((j1 - base < XC_FW_TILE) ? j1 - base : XC_FW_TILE);
+        __syncthreads();
+        if (j < j1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s_cur[q][threadIdx.x] = cur[q * m + j];
+                s_nxt[q][threadIdx.x] = nxt[q * m + j];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int i = 0; i < cnt; ++i) {
+                // frank_wolfe.py:392-397, the same expression per entry
+                const double tp = keep * s_cur[0][i] + alpha * s_nxt[0][i];
+                const double fp = keep * s_cur[1][i] + alpha * s_nxt[1][i];
+                const double fn = keep * s_cur[2][i] + alpha * s_nxt[2][i];
+                const double tn = keep * s_cur[3][i] + alpha * s_nxt[3][i];
+                sum += fw_metric<double>(metric, tp, fp, fn, tn);
+            }
+        }
+    }
+    if (live) partials[(int64_t)blockIdx.y * n_alpha + t] = sum;
+}
+
+} // namespace xc
+
+extern "C" {
+
+int xc_fw_gradient(int64_t m, const double *stats, const xc_metric *metric_host, double div, int negate,
+                   double *a, double *b, void *stream) {
+    if (m < 1 || !stats || !metric_host || !a || !b) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_fw_gradient: bad argument");
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_fw_gradient: unknown metric %d", metric_host->base);
+    const int blocks = (int)((m + XC_BLOCK - 1) / XC_BLOCK);
+    hipLaunchKernelGGL(xc::fw_gradient_kernel, dim3(blocks), dim3(XC_BLOCK), 0, xc::as_stream(stream), m, stats,
+                       *metric_host, div, negate, a, b);
+    XC_CHECK_LAUNCH("fw_gradient_kernel");
+    return XC_OK;
+}
+
+int xc_fw_alpha_chunks(int64_t m) {
+    const int64_t tiles = (m + XC_FW_TILE - 1) / XC_FW_TILE;
+    return (int)(tiles < 1 ? 1 : (tiles > 64 ? 64 : tiles));
+}
+
+int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_metric *metric_host, int n_alpha,
+                      const double *alphas, double *partials, void *stream) {
+    if (m < 1 || n_alpha < 1 || !cur || !nxt || !metric_host || !alphas || !partials)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_fw_alpha_curve: bad argument");
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_fw_alpha_curve: unknown metric %d", metric_host->base);
+    const int chunks = xc_fw_alpha_chunks(m);
+    // whole tiles per chunk, so a chunk's labels are summed in ascending order tile by tile
+    const int64_t tiles = (m + XC_FW_TILE - 1) / XC_FW_TILE;
+    const int64_t per_chunk = ((tiles + chunks - 1) / chunks) * XC_FW_TILE;
+    const int gx = (n_alpha + XC_FW_TILE - 1) / XC_FW_TILE;
+    hipLaunchKernelGGL(xc::fw_alpha_curve_kernel, dim3(gx, chunks), dim3(XC_FW_TILE), 0, xc::as_stream(stream), m, cur,
+                       nxt, *metric_host, n_alpha, alphas, per_chunk, partials);
+    XC_CHECK_LAUNCH("fw_alpha_curve_kernel");
+    return XC_OK;
+}
+
+} // extern "C"

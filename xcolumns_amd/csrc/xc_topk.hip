@@ -24,6 +24,8 @@ struct TopkParams {
     const T *data;
     const T *a;
     const T *b;
+    const int32_t *row_cls; // optional: row i uses a + row_cls[i] * ld, b + row_cls[i] * ld
+    int64_t ld;
     int k;
     int keep_scores;
     int32_t *out_indices;
@@ -92,18 +94,20 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
         const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
 
         int32_t *o_idx = P.out_indices + row * k;
-        T *o_dat = P.out_data + row * k;
+        T *o_dat = P.out_data ? P.out_data + row * k : nullptr;
         T *o_eta = P.out_eta ? P.out_eta + row * k : nullptr;
 
         T gain[CH];
         key_t key[CH];
         bool sel[CH];
+        // one weighted classifier per row (frank_wolfe.py:153-168) or one for all rows
+        const int64_t w_off = P.row_cls ? (int64_t)P.row_cls[row] * P.ld : 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const bool valid = lane + XC_WAVE * c < r;
             T g = cur.eta[c];
-            if (P.a) g = g * P.a[cur.idx[c]]; // numba_csr_functions.py:608-609
-            if (P.b) g = g + P.b[cur.idx[c]]; // :610-611
+            if (P.a) g = g * P.a[w_off + cur.idx[c]]; // numba_csr_functions.py:608-609
+            if (P.b) g = g + P.b[w_off + cur.idx[c]]; // :610-611
             gain[c] = g;
             key[c] = valid ? KeyOf<T>::make(g) : (key_t)0;
             sel[c] = false;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
             if (sel[c]) {
                 const int slot = base + __popcll(mask & lanemask_lt());
                 o_idx[slot] = cur.idx[c];
-                o_dat[slot] = P.keep_scores ? gain[c] : (T)1;
+                if (o_dat) o_dat[slot] = P.keep_scores ? gain[c] : (T)1;
                 if (o_eta) o_eta[slot] = cur.eta[c];
             }
             base += __popcll(mask);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
         // :599-601: slots a short row leaves unused keep column 0 / value 1
         if (lane >= n_sel && lane < k) {
             o_idx[lane] = 0;
-            o_dat[lane] = (T)1;
+            if (o_dat) o_dat[lane] = (T)1;
             if (o_eta) o_eta[lane] = (T)0;
         }
 
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
 template <typename T, bool FILL>
 __global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
     int64_t n, const int32_t *indptr, const int32_t *indices, const T *data, T th,
-    const T *a, const T *b, int32_t *out_counts, const int32_t *out_indptr,
+    const T *a, const T *b, int64_t ld, const int32_t *row_cls, int32_t *out_counts, const int32_t *out_indptr,
     int32_t *out_indices, int n_waves) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
     for (int64_t row = wave; row < n; row += n_waves) {
         const int s = indptr[row];
         const int r = indptr[row + 1] - s;
+        const int64_t w_off = row_cls ? (int64_t)row_cls[row] * ld : 0;
         int base = 0;
         for (int p0 = 0; p0 < r; p0 += XC_WAVE) {
             const int p = p0 + lane;
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
             if (p < r) {
                 col = indices[s + p];
                 T g = data[s + p];
-                if (a) g = g * a[col];
-                if (b) g = g + b[col];
+                if (a) g = g * a[w_off + col];
+                if (b) g = g + b[w_off + col];
                 keep = g >= th;
             }
             const unsigned long long mask = __ballot(keep);
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
 
 template <typename T>
 static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
-                       int k, const void *a, const void *b, int keep_scores, int32_t *out_indices,
+                       int k, const void *a, const void *b, int64_t ld, const int32_t *row_cls, int keep_scores,
+                       int32_t *out_indices,
                        void *out_data, void *out_eta, uint8_t *out_sel, int ch, hipStream_t st) {
     TopkParams<T> P;
     P.n = n;
@@ -208,6 +214,8 @@ static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices,
     P.data = static_cast<const T *>(data);
     P.a = static_cast<const T *>(a);
     P.b = static_cast<const T *>(b);
+    P.row_cls = row_cls;
+    P.ld = ld;
     P.k = k;
     P.keep_scores = keep_scores;
     P.out_indices = out_indices;
@@ -243,16 +251,16 @@ int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const 
     if (n == 0) return XC_OK;
     hipStream_t st = xc::as_stream(stream);
     if (dtype == XC_F32)
-        xc::launch_topk<float>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
+        xc::launch_topk<float>(n, indptr, indices, data, k, a, b, 0, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
     else
-        xc::launch_topk<double>(n, indptr, indices, data, k, a, b, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
+        xc::launch_topk<double>(n, indptr, indices, data, k, a, b, 0, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
     XC_CHECK_LAUNCH("topk_csr_kernel");
     return XC_OK;
 }
 
 static int threshold_common(bool fill, int64_t n, const int32_t *indptr, const int32_t *indices,
                             const void *data, int dtype, double th, const void *a, const void *b,
-                            int32_t *out_counts, const int32_t *out_indptr, int32_t *out_indices,
+                            int64_t ld, const int32_t *row_cls, int32_t *out_counts, const int32_t *out_indptr, int32_t *out_indices,
                             void *stream) {
     if (n < 0 || !indptr) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_csr: NULL pointer or negative n");
     if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_csr: unknown dtype %d", dtype);
@@ -265,17 +273,17 @@ static int threshold_common(bool fill, int64_t n, const int32_t *indptr, const i
         auto aa = static_cast<const float *>(a);
         auto bb = static_cast<const float *>(b);
         if (fill)
-            hipLaunchKernelGGL((xc::threshold_csr_kernel<float, true>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, (float)th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<float, true>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, (float)th, aa, bb, ld, row_cls, out_counts, out_indptr, out_indices, n_waves);
         else
-            hipLaunchKernelGGL((xc::threshold_csr_kernel<float, false>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, (float)th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<float, false>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, (float)th, aa, bb, ld, row_cls, out_counts, out_indptr, out_indices, n_waves);
     } else {
         auto d = static_cast<const double *>(data);
         auto aa = static_cast<const double *>(a);
         auto bb = static_cast<const double *>(b);
         if (fill)
-            hipLaunchKernelGGL((xc::threshold_csr_kernel<double, true>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<double, true>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, th, aa, bb, ld, row_cls, out_counts, out_indptr, out_indices, n_waves);
         else
-            hipLaunchKernelGGL((xc::threshold_csr_kernel<double, false>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, th, aa, bb, out_counts, out_indptr, out_indices, n_waves);
+            hipLaunchKernelGGL((xc::threshold_csr_kernel<double, false>), dim3(blocks), dim3(XC_BLOCK), 0, st, n, indptr, indices, d, th, aa, bb, ld, row_cls, out_counts, out_indptr, out_indices, n_waves);
     }
     XC_CHECK_LAUNCH("threshold_csr_kernel");
     return XC_OK;
@@ -285,14 +293,53 @@ int xc_threshold_count_csr(int64_t n, const int32_t *indptr, const int32_t *indi
                            int dtype, double th, const void *a, const void *b, int32_t *out_counts,
                            void *stream) {
     if (n > 0 && !out_counts) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_count_csr: out_counts is NULL");
-    return threshold_common(false, n, indptr, indices, data, dtype, th, a, b, out_counts, nullptr, nullptr, stream);
+    return threshold_common(false, n, indptr, indices, data, dtype, th, a, b, 0, nullptr, out_counts, nullptr, nullptr, stream);
 }
 
 int xc_threshold_fill_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
                           int dtype, double th, const void *a, const void *b, const int32_t *out_indptr,
                           int32_t *out_indices, void *stream) {
     if (n > 0 && !out_indptr) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_fill_csr: out_indptr is NULL");
-    return threshold_common(true, n, indptr, indices, data, dtype, th, a, b, nullptr, out_indptr, out_indices, stream);
+    return threshold_common(true, n, indptr, indices, data, dtype, th, a, b, 0, nullptr, nullptr, out_indptr, out_indices, stream);
+}
+
+// ---- one weighted classifier per row (frank_wolfe.py:127-172) ----
+int xc_topk_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data, int dtype,
+                        int max_row_nnz, int k, const void *a, const void *b, int64_t ld,
+                        const int32_t *row_classifier, int32_t *out_indices, void *stream) {
+    if (n < 0 || !indptr || (n > 0 && (!out_indices || !a || !b || !row_classifier)) || ld < 0)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr_rowwise: NULL pointer or bad size");
+    if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_topk_csr_rowwise: k=%d outside 1..%d", k, XC_MAX_K);
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr_rowwise: unknown dtype %d", dtype);
+    const int ch = xc::chunks_for(max_row_nnz);
+    if (ch == 0)
+        return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_topk_csr_rowwise: a row holds %d entries, limit %d", max_row_nnz, XC_MAX_ROW_NNZ);
+    if (n == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    // only the chosen column ids are produced: the prediction's values are all ones
+    if (dtype == XC_F32)
+        xc::launch_topk<float>(n, indptr, indices, data, k, a, b, ld, row_classifier, 0, out_indices, nullptr, nullptr, nullptr, ch, st);
+    else
+        xc::launch_topk<double>(n, indptr, indices, data, k, a, b, ld, row_classifier, 0, out_indices, nullptr, nullptr, nullptr, ch, st);
+    XC_CHECK_LAUNCH("topk_csr_kernel (rowwise)");
+    return XC_OK;
+}
+
+int xc_threshold_count_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
+                                   int dtype, double th, const void *a, const void *b, int64_t ld,
+                                   const int32_t *row_classifier, int32_t *out_counts, void *stream) {
+    if (n > 0 && (!out_counts || !row_classifier))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_count_csr_rowwise: NULL pointer");
+    return threshold_common(false, n, indptr, indices, data, dtype, th, a, b, ld, row_classifier, out_counts, nullptr, nullptr, stream);
+}
+
+int xc_threshold_fill_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,
+                                  int dtype, double th, const void *a, const void *b, int64_t ld,
+                                  const int32_t *row_classifier, const int32_t *out_indptr, int32_t *out_indices,
+                                  void *stream) {
+    if (n > 0 && (!out_indptr || !row_classifier))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_fill_csr_rowwise: NULL pointer");
+    return threshold_common(true, n, indptr, indices, data, dtype, th, a, b, ld, row_classifier, nullptr, out_indptr, out_indices, stream);
 }
 
 } // extern "C"

@@ -228,6 +228,10 @@ def host_values(spec: MetricSpec, tp, fp, fn, tn):
         _lib.XC_M_GMEAN: lambda: binary_gmean_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
         _lib.XC_M_HMEAN: lambda: binary_hmean_on_conf_matrix(tp, fp, fn, tn, spec.epsilon),
         _lib.XC_M_ACCURACY: lambda: binary_accuracy_on_conf_matrix(tp, fp, fn, tn),
+        # frank_wolfe.py:925-929
+        _lib.XC_M_RECALL_PRECISION_MIX: lambda: (
+            (1 - spec.alpha) * binary_recall_on_conf_matrix(tp, fp, fn, tn, spec.epsilon)
+            + spec.alpha * binary_precision_on_conf_matrix(tp, fp, fn, tn, spec.epsilon)),
     }
     base = table[spec.base]()
     if spec.mixed:
