@@ -149,3 +149,104 @@ def test_sharded_bca_two_ranks_gloo(oref):
     u_top = oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n)
     assert u0[0] > u_top
     assert abs(u0[-1] - mo["utilities"][-1]) < 2e-4, (u0, mo["utilities"])
+
+
+# ---------------------------------------------------------------------------
+# Frank-Wolfe over two row shards
+# ---------------------------------------------------------------------------
+
+class OracleFwEngine:
+    """CPU stand-in for xcolumns_amd.frank_wolfe.FwEngine over one rank's rows (test infrastructure):
+    same interface, the per-row work done by the oracle, the all-reduce by the product's comm."""
+
+    def __init__(self, y_true, y_proba, k, objective, maximize, normalize, skip_tn, comm=None, n_total=None):
+        from oracle import fw_ref, ref
+        self.fw, self.ref = fw_ref, ref
+        self.yt, self.yp, self.k, self.comm = y_true, y_proba, k, comm
+        self.maximize, self.normalize, self.skip_tn = maximize, normalize, skip_tn
+        self.n_total = y_proba.shape[0] if n_total is None else n_total
+        s = objective.spec
+        self.mt = fw_ref.FwMetric(base=s.base, average=objective.average, epsilon=s.epsilon, beta=s.beta, k=s.kf,
+                                  mixed=s.mixed, alpha=s.alpha, m=s.mf)
+
+    def confusion_of(self, a, b):
+        pred = self.ref.predict_weighted_per_instance(self.yp, self.k, th=0.0, a=a, b=b)
+        tp, fp, fn, _ = self.ref.calculate_confusion_matrix(self.yt, pred, skip_tn=True)
+        t = torch.from_numpy(np.stack([tp, fp, fn]))
+        self.comm.all_reduce(t)                       # the ONE collective of an iteration
+        c = t.numpy().astype(self.yt.dtype)
+        if self.normalize:
+            c = c / self.n_total
+        tn = np.full_like(c[0], -1) if self.skip_tn else -c[0] - c[1] - c[2] + (1 if self.normalize else self.n_total)
+        return np.stack([c[0], c[1], c[2], tn]).astype(np.float64)
+
+    def utility(self, stats):
+        return float(self.fw.metric_value(self.mt, *stats))
+
+    def next_classifier(self, stats):
+        _, gtp, gfp, gfn, gtn = self.fw.metric_value_and_gradient(self.mt, *stats)
+        a, b = gtp - gfp - gfn + gtn, gfp - gtn
+        return (a, b) if self.maximize else (-a, -b)
+
+    def best_alpha(self, cur, nxt, algo, eps, step):
+        f = lambda al: self.fw.metric_value(self.mt, *((1 - al) * cur + al * nxt))
+        return (self.fw.uniform_search(0, 1, step, f) if algo == "uniform" else self.fw.ternary_search(0, 1, eps, f))[0]
+
+
+def _fw_problem():
+    rng = np.random.default_rng(77)
+    n, m, r = 1501, 60, 10
+    cols = np.concatenate([np.sort(rng.choice(m, r, replace=False)) for _ in range(n)]).astype(np.int32)
+    w = 0.05 + 0.95 * rng.random(m) ** 2
+    eta = (rng.random(n * r) ** 2) * w[cols]
+    indptr = (np.arange(n + 1) * r).astype(np.int32)
+    Yp = csr_matrix((eta, cols, indptr), shape=(n, m))
+    Yt = csr_matrix(((rng.random(n * r) < eta).astype(np.float64), cols.copy(), indptr.copy()), shape=(n, m))
+    return Yt, Yp
+
+
+def _fw_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xcolumns_amd.distributed import TorchComm, find_classifier_using_fw_sharded, shard_csr
+    from xcolumns_amd.metrics import macro_f1_score_on_conf_matrix
+
+    Yt, Yp = _fw_problem()
+    comm = TorchComm()
+    clf, meta = find_classifier_using_fw_sharded(shard_csr(Yt, world, rank), shard_csr(Yp, world, rank),
+                                                 macro_f1_score_on_conf_matrix, 3, comm, skip_tn=True, max_iters=5,
+                                                 alpha_uniform_search_step=0.01, return_meta=True,
+                                                 engine_factory=OracleFwEngine)
+    q.put((rank, clf.a.copy(), clf.b.copy(), clf.p.copy(), meta["utilities"], meta["alphas"], meta["iters"], comm.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_frank_wolfe_two_ranks_gloo():
+    from oracle import fw_ref as fw
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fw_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, a0, b0, p0, u0, al0, it0, calls0), (_, a1, b1, p1, u1, al1, it1, calls1) = res
+    # every rank ends with the same classifier, trace and stopping decision
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and np.array_equal(p0, p1)
+    assert u0 == u1 and al0 == al1 and it0 == it1
+    # one row-count exchange, then one all-reduce per weighted classifier (initial + one per iteration)
+    assert calls0 == calls1 == 1 + 1 + it0
+    # and it is the single-process result: the all-reduced counts are exact
+    Yt, Yp = _fw_problem()
+    A, B, P, meta = fw.find_classifier_using_fw(Yt, Yp, fw.FwMetric(base=fw.FBETA, average="macro"), 3, skip_tn=True,
+                                               max_iters=5, alpha_uniform_search_step=0.01)
+    assert meta["iters"] == it0 and np.array_equal(A, a0) and np.array_equal(B, b0) and np.array_equal(P, p0)
+    assert np.allclose(meta["utilities"], u0, rtol=1e-13) and list(meta["alphas"]) == list(al0)

@@ -148,3 +148,27 @@ class _FixedWaves:
 
     def next(self, changed_prev=None):
         return self.w
+
+
+# ---------------------------------------------------------------------------
+# Frank-Wolfe over row shards
+# ---------------------------------------------------------------------------
+
+def find_classifier_using_fw_sharded(y_true_local: csr_matrix, y_proba_local: csr_matrix, metric_func, k: int,
+                                     comm: TorchComm, **kwargs):
+    """`find_classifier_using_fw` with the rows sharded over the ranks of `comm`: every rank holds
+    rows [lo, hi) of `y_true` / `y_proba` and runs the same iteration on them; the only exchange is
+    ONE all-reduce of the 3m label counts per weighted classifier (the FW iteration is exactly
+    data-parallel: top-k and confusion counts are per row, everything else is O(m) and replicated).
+    The counts are integers, so every rank sees bit-identical statistics and takes the same steps;
+    the returned classifier is identical on all ranks and equal to the single-process one."""
+    from .frank_wolfe import find_classifier_using_fw
+
+    rows = torch.tensor([y_proba_local.shape[0]], dtype=torch.int64)
+    dev = None
+    if torch.cuda.is_available() and dist.get_backend(comm.group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rows = rows.to(dev)
+    comm.all_reduce(rows)
+    return find_classifier_using_fw(y_true_local, y_proba_local, metric_func, k, comm=comm,
+                                    n_total=int(rows.item()), **kwargs)

@@ -455,7 +455,8 @@ def find_classifier_using_fw(
     `metric_func` of the confusion matrix on (`y_true`, `y_proba`); frank_wolfe.py:407-690, same
     arguments, stopping rule and ``meta`` ("alphas", "classifiers_utilities", "utilities", "time",
     "iters").  Extra keyword arguments: ``comm`` / ``n_total`` (rows sharded over ranks: `y_true`,
-    `y_proba` are this rank's rows, counts are all-reduced once per iteration)."""
+    `y_proba` are this rank's rows, counts are all-reduced once per iteration; see
+    :func:`xcolumns_amd.distributed.find_classifier_using_fw_sharded`)."""
     log_info("Starting searching for optimal randomized classifier using Frank-Wolfe algorithm ...", verbose)
     log_info(f"  Optimization direction: {'maximize' if maximize else 'minimize'}, "
              f"{f'budget k: {k}' if k > 0 else ''}", verbose)
@@ -475,6 +476,7 @@ def find_classifier_using_fw(
     n, m = y_proba.shape
     comm = kwargs.pop("comm", None)
     n_total = kwargs.pop("n_total", None)
+    engine_factory = kwargs.pop("engine_factory", FwEngine)
 
     log_info(f"  Initializing initial {init_classifier if isinstance(init_classifier, str) else 'custom'} classifier ...",
              verbose)
@@ -507,7 +509,8 @@ def find_classifier_using_fw(
             "Unsupported type of init_classifier, it should be in ['random', 'top'], or a tuple of two np.ndarray "
             "or torch.Tensor of shape (y_true.shape[1], )")
 
-    eng = FwEngine(y_true, y_proba, k, objective, maximize, normalize_conf_matrix, skip_tn, comm=comm, n_total=n_total)
+    eng = engine_factory(y_true, y_proba, k, objective, maximize, normalize_conf_matrix, skip_tn, comm=comm,
+                         n_total=n_total)
     stats = eng.confusion_of(A[0], B[0])
     utility_i = eng.utility(stats)
     meta: Dict[str, Any] = {"alphas": [], "classifiers_utilities": [utility_i], "utilities": [utility_i], "time": time()}
