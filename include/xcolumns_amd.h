@@ -334,7 +334,9 @@ int xc_fw_gradient(int64_t m, const double *stats, const xc_metric *metric_host,
  * left as partial sums partials[c * n_alpha + t], c < xc_fw_alpha_chunks(m), to be
  * added over c in ascending order.  The caller picks the step (first maximum for the
  * uniform search, utils.py:174-184; two points per step for the ternary one,
- * :187-201). */
+ * :187-201).  Up to 16 points are evaluated with the reference's exact expression
+ * and IEEE division; a longer scan mixes with one fma per entry and divides to
+ * ~1 ulp (differences of the size of the summation-order ones). */
 int xc_fw_alpha_chunks(int64_t m);
 int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt,
                       const xc_metric *metric_host, int n_alpha, const double *alphas,

@@ -15,4 +15,6 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_fetch.log 2>&1 || { echo "fetch run failed"; tail -5 $OUT/prof_${TAG}_fetch.log; exit 1; }
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_write -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_write.log 2>&1 || { echo "write run failed"; tail -5 $OUT/prof_${TAG}_write.log; exit 1; }
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/prof_${TAG}_sq -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_sq.log 2>&1 || { echo "sq run failed"; tail -5 $OUT/prof_${TAG}_sq.log; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/prof_${TAG}_tcc -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_tcc.log 2>&1 || { echo "tcc run failed"; tail -5 $OUT/prof_${TAG}_tcc.log; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/prof_${TAG}_ea -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/prof_${TAG}_ea.log 2>&1 || { echo "ea run failed"; tail -5 $OUT/prof_${TAG}_ea.log; exit 1; }
 find $OUT/prof_${TAG}_trace $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write -type f | head -30

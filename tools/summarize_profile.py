@@ -79,6 +79,21 @@ if f:
         avg = sum(vals) / len(vals)
         print(f"{c:24s} {avg:16.1f}" + (f"   per row {avg / rows_per_launch:10.1f}" if rows_per_launch else ""))
 
+for ctr, title in (("tcc", "L2 (TCC) requests"), ("ea", "L2 <-> fabric (EA) requests and L1 -> L2 reads")):
+    f = one(f"prof_{tag}_{ctr}/**/*_counter_collection.csv")
+    if not f:
+        continue
+    per = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "bca_sweep" in r["Kernel_Name"]:
+            per[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+    print(f"\n## {title} of bca_sweep_csr_kernel, average over the timed launches"
+          + (f", per row ({rows_per_launch} rows per launch)" if rows_per_launch else ""))
+    for c, d in sorted(per.items()):
+        vals = [d[k] for k in sorted(d)][-timed:]
+        avg = sum(vals) / len(vals)
+        print(f"{c:24s} {avg:16.1f}" + (f"   per row {avg / rows_per_launch:10.2f}" if rows_per_launch else ""))
+
 if traffic_json and "fetch" in sweep_bytes and "write" in sweep_bytes:
     import json
     out = {

@@ -15,6 +15,7 @@
 #include "xc_host.h"
 
 #define XC_FW_TILE 256
+#define XC_FW_EXACT_POINTS 16 /* up to this many alphas: the reference's exact arithmetic */
 
 namespace xc {
 
@@ -41,6 +42,19 @@ __device__ __forceinline__ Dual nsqrt(Dual a) {
     return Dual(s, h * a.d0, h * a.d1, h * a.d2, h * a.d3);
 }
 __device__ __forceinline__ double nsqrt(double a) { return sqrt(a); }
+
+// float64 with the ~1-ulp division of xc_common.h (v_rcp_f64 + two Newton steps): used by the step-size
+// scan, whose label sums already differ from numpy's pairwise ones in the last bits
+struct FastD {
+    double v;
+    __device__ FastD() {}
+    __device__ FastD(double x) : v(x) {}
+};
+__device__ __forceinline__ FastD operator+(FastD a, FastD b) { return FastD(a.v + b.v); }
+__device__ __forceinline__ FastD operator-(FastD a, FastD b) { return FastD(a.v - b.v); }
+__device__ __forceinline__ FastD operator*(FastD a, FastD b) { return FastD(a.v * b.v); }
+__device__ __forceinline__ FastD operator/(FastD a, FastD b) { return FastD(fdiv<false>(a.v, b.v)); }
+__device__ __forceinline__ FastD nsqrt(FastD a) { return FastD(sqrt(a.v)); }
 
 // metrics.py formulas in the reference's operation order (the file is compiled with
 // -ffp-contract=off), for N = double or Dual
@@ -106,12 +120,16 @@ __global__ __launch_bounds__(XC_BLOCK) void fw_gradient_kernel(int64_t m, const 
 }
 
 // partials[chunk][t] = sum over the chunk's labels of psi((1 - alpha_t) * cur_j + alpha_t * nxt_j)
+// EXACT: the reference's expression and IEEE division (two-point ternary steps).  Otherwise (the
+// 10^4-point uniform scan, VALU-bound): the mix as one fma per entry, cur + alpha * (nxt - cur), and
+// the ~1-ulp division -- differences of the size of the summation-order ones.
+template <bool EXACT>
 __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, const double *cur, const double *nxt,
                                                                    xc_metric metric, int n_alpha,
                                                                    const double *alphas, int64_t per_chunk,
                                                                    double *partials) {
-    __shared__ double s_cur[4][XC_FW_TILE];
-    __shared__ double s_nxt[4][XC_FW_TILE];
+    __shared__ double s_cur[XC_FW_TILE][4];
+    __shared__ double s_nxt[XC_FW_TILE][4]; // !EXACT: nxt - cur
     const int t = blockIdx.x * XC_FW_TILE + threadIdx.x;
     const bool live = t < n_alpha;
     const double alpha = live ? alphas[t] : 0.0;
@@ -126,19 +144,28 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
         if (j < j1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                s_cur[q][threadIdx.x] = cur[q * m + j];
-                s_nxt[q][threadIdx.x] = nxt[q * m + j];
+                const double c = cur[q * m + j], x = nxt[q * m + j];
+                s_cur[threadIdx.x][q] = c;
+                s_nxt[threadIdx.x][q] = EXACT ? x : x - c;
             }
         }
         __syncthreads();
         if (live) {
+#pragma unroll 4
             for (int i = 0; i < cnt; ++i) {
-                // frank_wolfe.py:392-397, the same expression per entry
-                const double tp = keep * s_cur[0][i] + alpha * s_nxt[0][i];
-                const double fp = keep * s_cur[1][i] + alpha * s_nxt[1][i];
-                const double fn = keep * s_cur[2][i] + alpha * s_nxt[2][i];
-                const double tn = keep * s_cur[3][i] + alpha * s_nxt[3][i];
-                sum += fw_metric<double>(metric, tp, fp, fn, tn);
+                if (EXACT) { // frank_wolfe.py:392-397, the same expression per entry
+                    const double tp = keep * s_cur[i][0] + alpha * s_nxt[i][0];
+                    const double fp = keep * s_cur[i][1] + alpha * s_nxt[i][1];
+                    const double fn = keep * s_cur[i][2] + alpha * s_nxt[i][2];
+                    const double tn = keep * s_cur[i][3] + alpha * s_nxt[i][3];
+                    sum += fw_metric<double>(metric, tp, fp, fn, tn);
+                } else {
+                    const FastD tp(__builtin_fma(alpha, s_nxt[i][0], s_cur[i][0]));
+                    const FastD fp(__builtin_fma(alpha, s_nxt[i][1], s_cur[i][1]));
+                    const FastD fn(__builtin_fma(alpha, s_nxt[i][2], s_cur[i][2]));
+                    const FastD tn(__builtin_fma(alpha, s_nxt[i][3], s_cur[i][3]));
+                    sum += fw_metric<FastD>(metric, tp, fp, fn, tn).v;
+                }
             }
         }
     }
@@ -177,8 +204,12 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_
     const int64_t tiles = (m + XC_FW_TILE - 1) / XC_FW_TILE;
     const int64_t per_chunk = ((tiles + chunks - 1) / chunks) * XC_FW_TILE;
     const int gx = (n_alpha + XC_FW_TILE - 1) / XC_FW_TILE;
-    hipLaunchKernelGGL(xc::fw_alpha_curve_kernel, dim3(gx, chunks), dim3(XC_FW_TILE), 0, xc::as_stream(stream), m, cur,
-                       nxt, *metric_host, n_alpha, alphas, per_chunk, partials);
+    if (n_alpha <= XC_FW_EXACT_POINTS)
+        hipLaunchKernelGGL(xc::fw_alpha_curve_kernel<true>, dim3(gx, chunks), dim3(XC_FW_TILE), 0, xc::as_stream(stream),
+                           m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials);
+    else
+        hipLaunchKernelGGL(xc::fw_alpha_curve_kernel<false>, dim3(gx, chunks), dim3(XC_FW_TILE), 0, xc::as_stream(stream),
+                           m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials);
     XC_CHECK_LAUNCH("fw_alpha_curve_kernel");
     return XC_OK;
 }
