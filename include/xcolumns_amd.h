@@ -235,7 +235,10 @@ int xc_utility_finish_host(const double *partials, double *out_host,
  *                visited row's NEW prediction into it ({tp, fp} per label) -- when
  *                all rows are visited this IS the sweep-boundary recompute
  *                (block_coordinate.py:465-467), no second pass -- and the number of
- *                changed rows into acc[2m]
+ *                changed rows into acc[2m].  With `shadow` AND `acc` (concurrent sweep)
+ *                the float64 records `tpfp` are left as they were at the sweep start:
+ *                the sweep reads only the shadow, and xc_bca_commit_utility rewrites
+ *                tpfp and shadow from acc afterwards
  *   greedy       first sweep of init_y_pred="greedy": rows are added as they are
  *                visited (:243 skipped, stats start from zero)
  *   n_waves      number of wavefronts that walk `order` concurrently: wave w takes

@@ -15,6 +15,9 @@ base, tag = sys.argv[1], sys.argv[2]
 timed = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 traffic_json = sys.argv[4] if len(sys.argv) > 4 else None
 rows_per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else None
+# bytes per launch that the sweep reads as WIDE coalesced streams (16 B per lane: the packed row
+# entries): the share of FETCH_SIZE that gfx950 tallies at half (MI355X_MICROARCH.md, HBM section)
+wide_stream_bytes = float(sys.argv[6]) if len(sys.argv) > 6 else None
 sweep_bytes = {}
 
 
@@ -96,16 +99,25 @@ for ctr, title in (("tcc", "L2 (TCC) requests"), ("ea", "L2 <-> fabric (EA) requ
 
 if traffic_json and "fetch" in sweep_bytes and "write" in sweep_bytes:
     import json
+    raw = sweep_bytes["fetch"]
+    if wide_stream_bytes is not None:
+        corrected = raw + 0.5 * wide_stream_bytes
+        how = (f"FETCH_SIZE + half of the {wide_stream_bytes / 1e6:.0f} MB the launch reads as 16-B-per-lane coalesced "
+               "streams (the packed row entries; gfx950 tallies such 128-B requests at 64 B: MI355X_MICROARCH.md HBM "
+               "section, confirmed here on colsum_csr_kernel, 40.0 MB read / 20.0 MB reported); the scattered 8-byte "
+               "record gathers are 64-B requests counted in full (TCC_EA0_RDREQ x 64 B = FETCH_SIZE in the same run)")
+    else:
+        corrected = 2 * raw
+        how = "FETCH_SIZE doubled (gfx950 reports half of wide coalesced streams: MI355X_MICROARCH.md)"
     out = {
         "kernel": "bca_sweep_csr_kernel",
         "tag": tag,
-        "fetch_size_bytes_raw": sweep_bytes["fetch"],
-        "fetch_size_bytes_corrected": 2 * sweep_bytes["fetch"],
+        "fetch_size_bytes_raw": raw,
+        "fetch_size_bytes_corrected": corrected,
         "write_size_bytes": sweep_bytes["write"],
-        "hbm_bytes_per_launch": 2 * sweep_bytes["fetch"] + sweep_bytes["write"],
+        "hbm_bytes_per_launch": corrected + sweep_bytes["write"],
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, average over the timed launches; "
-                "FETCH_SIZE doubled (gfx950 reports half of coalesced streams: MI355X_MICROARCH.md, confirmed on "
-                "colsum_csr_kernel: 40.0 MB read, 20.0 MB reported); counters include Infinity-Cache hits",
+                + how + "; the counters sit at the fabric, so Infinity-Cache hits are included",
     }
     json.dump(out, open(traffic_json, "w"), indent=1)
     print(f"\nwrote {traffic_json}")

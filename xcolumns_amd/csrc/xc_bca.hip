@@ -245,7 +245,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         if (P.orphans && !greedy && lane < k) {
             const int oid = P.orphans[row * k + lane];
             if (oid >= 0) {
-                atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
+                if (!(SHADOW && P.acc)) atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
                 if (P.shadow) atomic_add_f32(P.shadow + (int64_t)oid * 2 + 1, -1.0f);
             }
         }
@@ -409,22 +409,34 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
         row_changed = __ballot(any_change) != 0ull;
         if (EXACT || greedy || !P.validate || !row_changed || attempt >= XC_MAX_RETRY) break;
+        // first only the records of the labels this row adds or drops (2-3 of its ~50
+        // candidates: inactive lanes issue no request) ...
         bool moved = false;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            if (SHADOW) {
-                const float2_t now = __builtin_bit_cast(
-                    float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
-                moved = moved || ((in_new[c] != in_old[c]) && (now.x != rec32[c].x || now.y != rec32[c].y));
-                rec32[c] = now;
-            } else {
-                const double2_t now = __builtin_bit_cast(
-                    double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
-                moved = moved || ((in_new[c] != in_old[c]) && (now.x != rec64[c].x || now.y != rec64[c].y));
-                rec64[c] = now;
+            if (in_new[c] != in_old[c]) {
+                if (SHADOW) {
+                    const float2_t now = __builtin_bit_cast(
+                        float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
+                    moved = moved || now.x != rec32[c].x || now.y != rec32[c].y;
+                } else {
+                    const double2_t now = __builtin_bit_cast(
+                        double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
+                    moved = moved || now.x != rec64[c].x || now.y != rec64[c].y;
+                }
             }
         }
         if (__ballot(moved) == 0ull) break;
+        // ... and only after a conflict every candidate's record, to score the row again
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (SHADOW)
+                rec32[c] = __builtin_bit_cast(
+                    float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
+            else
+                rec64[c] = __builtin_bit_cast(
+                    double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
+        }
         } // retry
         XC_STAMP(3); // top-k
         // The from-scratch recompute of the sweep boundary (block_coordinate.py:465-467:
@@ -481,8 +493,13 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                         }
                     } else if (in_new[c] != in_old[c]) {
                         const double sgn = in_new[c] ? 1.0 : -1.0;
-                        atomic_add_f64(st + 0, sgn * ed);
-                        atomic_add_f64(st + 1, sgn * omd);
+                        // a sweep that gathers the shadow AND accumulates the boundary's from-scratch
+                        // statistics never reads the float64 records before the commit kernel
+                        // overwrites them from `acc`: their delta atomics would be dead work
+                        if (!(SHADOW && P.acc)) {
+                            atomic_add_f64(st + 0, sgn * ed);
+                            atomic_add_f64(st + 1, sgn * omd);
+                        }
                         if (P.shadow) { // keep the float32 copy in step
                             float *sh = P.shadow + (int64_t)cur.idx[c] * 2;
                             atomic_add_f32(sh + 0, (float)(sgn * ed));
