@@ -140,7 +140,6 @@ def main():
 
     ev_pairs = []
     waves_used = []
-    state = {"changed": None}
     # events are created up front: only their attachment to the sweep dispatch is in the timed region
     ev_pool = []
     for _ in range(args.steps):
@@ -148,36 +147,61 @@ def main():
         _lib.call("xc_event_create", ctypes.byref(e0))
         _lib.call("xc_event_create", ctypes.byref(e1))
         ev_pool.append((e0, e1))
-    host_t = {"sweep_call": 0.0, "boundary_call": 0.0}
+    host_t = {"enqueue": 0.0, "wait_result": 0.0}
+    pipelined = eng.can_pipeline(n) and not policy.sequential
+    NEVER = -1e300  # tolerance: the stopping rule never fires, every run does exactly K sweeps
 
-    def step(s, timed):
-        """One BCA iteration exactly as predict_using_bc_with_0approx runs it."""
-        n_waves = policy.next(state["changed"])
-        if timed:
-            # HIP events attached to the sweep dispatch itself, on the stream it runs on
-            e0, e1 = ev_pool[len(ev_pairs)]
-            _lib.call("xc_bca_time_next_sweep", e0, e1)
-        t_a = time.perf_counter()
-        eng.sweep(orders[s], n, n_waves, greedy=False)
-        t_b = time.perf_counter()
-        if timed:
-            ev_pairs.append((e0, e1))
-            waves_used.append(n_waves)
-        u = eng.recompute_utility_sum(n_u) / m
-        state["changed"] = eng.rows_changed()
-        if timed:
-            host_t["sweep_call"] += t_b - t_a
-            host_t["boundary_call"] += time.perf_counter() - t_b
-        return u
+    def run(first, last, old_sum, timed):
+        """Sweeps first..last-1 exactly as block_coordinate.run_bca_sweeps drives them: the stopping
+        rule and the wavefront policy are evaluated on the GPU at every boundary, the host enqueues
+        sweep j + 1 before it reads the result of sweep j (one D2H of 4 doubles per boundary)."""
+        out = []
+        if not pipelined:   # bca_waves = 1 (--waves 1): the host-paced exact loop
+            changed = None
+            for s in range(first, last):
+                if timed and os.environ.get("XC_BENCH_NO_EVENTS") != "1":
+                    e0, e1 = ev_pool[len(ev_pairs)]
+                    _lib.call("xc_bca_time_next_sweep", e0, e1)
+                    ev_pairs.append((e0, e1))
+                w = policy.next(changed)
+                eng.sweep(orders[s], n, w, greedy=False)
+                out.append(eng.recompute_utility_sum(n_u))
+                changed = eng.rows_changed()
+                if timed:
+                    waves_used.append(w)
+            return out
+        eng.pipeline_begin(old_sum, NEVER, float(m), True, policy, policy.next(None))
 
-    utilities = []
-    for s in range(args.warmup):
-        step(s, False)
-    state["changed"] = None
+        def collect(j):
+            t = time.perf_counter()
+            total, changed, waves, flag = eng.pipeline_result(j)
+            if timed:
+                host_t["wait_result"] += time.perf_counter() - t
+                waves_used.append(waves)
+            assert flag == 0, flag
+            out.append(total)
+
+        for s in range(first, last):
+            t = time.perf_counter()
+            if timed and os.environ.get("XC_BENCH_NO_EVENTS") != "1":
+                # HIP events attached to the sweep dispatch itself, on the stream it runs on
+                e0, e1 = ev_pool[len(ev_pairs)]
+                _lib.call("xc_bca_time_next_sweep", e0, e1)
+                ev_pairs.append((e0, e1))
+            eng.pipeline_step(orders[s], s, n_u)
+            if timed:
+                host_t["enqueue"] += time.perf_counter() - t
+            if s > first:
+                collect(s - 1)
+        collect(last - 1)
+        return out
+
+    u0_sum = u0 * m
+    run(0, args.warmup, u0_sum, False)
     # the timed steps are sweeps 1..K of a fresh run: back to the top-k prediction
     # (untimed), so the measured mix of changed / unchanged rows is a real run's
     eng.init_top()
-    eng.recompute_utility_sum(n_u)
+    u0_sum = eng.recompute_utility_sum(n_u)
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,8 +211,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.warmup, total):
-        utilities.append(step(s, True))
+    utilities = [u / m for u in run(args.warmup, total, u0_sum, True)]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -237,7 +260,8 @@ def main():
                             f"init top-k, skip_tn, float32 scores, float64 statistics",
                 "rows_per_gpu": n, "labels": m, "nnz_per_row": R_NNZ, "k": K,
                 "concurrent_wavefronts_per_sweep": waves_used,
-                "step": "sweep kernel + tp/fp recompute + (all-reduce) + utility + D2H",
+                "step": "sweep kernel (incl. from-scratch tp/fp recompute) + (all-reduce) + commit/utility "
+                        "+ stopping rule + D2H of the result",
             },
             "roofline": {
                 "kernel": "bca_sweep_csr_kernel<float,1>",
@@ -253,8 +277,9 @@ def main():
                 "frac_whole_step": b_sweep * n * world * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
                 "avg_kernel_ms": avg_sweep_s * 1e3,
             },
-            "host_ms_per_step": {"sweep_launch_call": host_t["sweep_call"] / args.steps * 1e3,
-                                 "boundary_call_incl_wait_for_sweep": host_t["boundary_call"] / args.steps * 1e3},
+            "host_ms_per_step": {"enqueue_sweep_and_boundary": host_t["enqueue"] / args.steps * 1e3,
+                                 "wait_for_previous_result": host_t["wait_result"] / args.steps * 1e3},
+            "loop": "device-side stopping rule, host one iteration behind" if pipelined else "host-paced (exact)",
             "utility_first_last": [utilities[0], utilities[-1]],
             "utility_top_k": u0,
         }

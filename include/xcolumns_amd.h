@@ -315,6 +315,63 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
                        const xc_metric *metric_host, double *partials, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The sweep loop without a host round trip per iteration.
+ *
+ * predict_using_bc_with_0approx decides after every sweep whether to run another
+ * (block_coordinate.py:486-493).  Here that rule -- and the wavefront-count policy
+ * of DESIGN.md "staleness" -- is evaluated on the GPU at the sweep boundary and
+ * left in a small control block; sweep j + 1 can then be enqueued before the host
+ * has seen the utility of sweep j: if the rule fired, the later launches find the
+ * stop flag and do nothing.  The host reads every boundary's result (utility sum,
+ * changed rows, wavefronts used, stop flag) one iteration late from a pinned ring.
+ *
+ * ctrl: float64[XC_CTRL_SIZE] on the device.  Ring slot s (s < XC_CTRL_RING_SLOTS) is
+ * the four doubles at ctrl[XC_CTRL_RING + 4 s]: {utility sum, rows changed,
+ * wavefronts of the sweep, 0 = continue | 1 = rule fired | 2 = step skipped}.
+ * ------------------------------------------------------------------------- */
+#define XC_CTRL_STOP 0
+#define XC_CTRL_OLD_SUM 1
+#define XC_CTRL_WAVES 2
+#define XC_CTRL_TOLERANCE 3
+#define XC_CTRL_DIVISOR 4
+#define XC_CTRL_MAXIMIZE 5
+#define XC_CTRL_POLICY_NUM 6
+#define XC_CTRL_WORLD 7
+#define XC_CTRL_MIN_WAVES 8
+#define XC_CTRL_MAX_WAVES 9
+#define XC_CTRL_FIXED_WAVES 10
+#define XC_CTRL_RING 16
+#define XC_CTRL_RING_SLOTS 8
+#define XC_CTRL_SIZE (XC_CTRL_RING + 4 * XC_CTRL_RING_SLOTS)
+
+/* Arm the control block: `old_utility_sum` = utility sum of the current prediction;
+ * the rule is (new/divisor - old/divisor < tolerance) for maximize, (> tolerance)
+ * otherwise (divisor = m for metric_aggregation "mean", 1 for "sum").  Wavefronts of
+ * the next sweep = fixed_waves if > 0, else max_waves when world > 1, else
+ * clamp(floor(policy_num / max(1, changed / world)), min_waves, max_waves);
+ * `first_waves` is used by the first sweep. */
+int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance, double divisor,
+                          int maximize, double policy_num, int world, int min_waves,
+                          int max_waves, int fixed_waves, int first_waves, void *stream);
+
+/* A full, non-greedy sweep over `order` (xc_bca_plan_sweep with acc), launched for
+ * max_waves wavefronts; runs only if the stop flag is clear, with ctrl's count. */
+int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed, int max_waves,
+                                const double *ctrl, void *stream);
+
+/* The boundary after it (the caller all-reduces acc in between when rows are
+ * sharded): commit + utility partials, then the rule and the policy on the GPU,
+ * the ring slot copied to host_ring[4 slot .. 4 slot + 3] (pinned) and `event`
+ * recorded.  Nothing here blocks. */
+int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_counted,
+                                   int skip_tn, double *ctrl, int slot, double *host_ring,
+                                   void *event, void *stream);
+
+int xc_event_synchronize(void *event);
+int xc_host_alloc_pinned(void **ptr, int64_t bytes);
+int xc_host_free_pinned(void *ptr);
+
+/* ---------------------------------------------------------------------------
  * Frank-Wolfe search for a randomized weighted classifier
  * (xcolumns/frank_wolfe.py:407-690).  An iteration is
  * xc_topk_csr with weights (a, b) -> xc_confusion_csr against y_true -> the two

@@ -555,3 +555,60 @@ def test_evaluation_metrics_golden():
         assert abs(f(L, P) - float(z["csr_" + name])) < 1e-12, name
         assert abs(f(z["ld"], z["pd"]) - float(z["dense_" + name])) < 1e-12, name
     assert np.allclose(pm.label_priors(z["ld"]), z["label_priors"], rtol=0, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------
+# the sweep loop with the stopping rule on the GPU (xc_bca_plan_*_pipelined)
+# ---------------------------------------------------------------------------
+
+def test_pipelined_loop_matches_the_stopping_rule_and_policy(oref):
+    """Default (concurrent) runs hand the stopping rule and the wavefront policy to the GPU and read
+    the results one iteration late.  The trace must be what the host-paced loop would produce: every
+    sweep but the last improved by >= tolerance, the last did not (or max_iters was hit); the
+    wavefronts of sweep j follow WavePolicy from the rows changed in sweep j - 1; the last utility is
+    the utility of the returned prediction; nothing ran after the rule fired."""
+    from xcolumns_amd.block_coordinate import WavePolicy, predict_optimizing_macro_f1_score_using_bc
+    from xcolumns_amd.synthetic import make_csr
+
+    n, m, k = 30000, 3000, 5
+    Y = make_csr(n, m, 40, seed=77, k=k)
+    for tol, max_iters in ((1e-5, 50), (-1.0, 4), (1e-6, 100)):
+        P, meta = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=3, tolerance=tol, max_iters=max_iters,
+                                                             return_meta=True, bca_diagnostics=True)
+        u = meta["utilities"]
+        assert meta["iters"] == len(u) <= max_iters
+        top = oref.predict_top_k(Y, k)
+        metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+
+        def util(pred):
+            tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, pred, skip_tn=True)
+            return oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n)
+
+        trace = [util(top)] + u
+        gains = np.diff(trace)
+        assert (gains[:-1] >= tol).all(), gains
+        assert gains[-1] < tol or len(u) == max_iters
+        assert abs(util(P) - u[-1]) < 1e-12           # the prediction returned is the one of the last boundary
+        pol = WavePolicy(n)
+        want = [pol.next(None)] + [pol.next(c) for c in meta["rows_changed"][:-1]]
+        assert meta["wavefronts"] == want, (meta["wavefronts"], want)
+
+
+def test_pipelined_and_host_paced_loops_agree(monkeypatch, oref):
+    """XCOLUMNS_BCA_PIPELINE=0 keeps the host in the loop; both loops must stop after the same sweep
+    with utilities that differ only by the concurrent sweep's run-to-run noise."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    from xcolumns_amd.synthetic import make_csr
+
+    Y = make_csr(20000, 2000, 40, seed=78, k=5)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("XCOLUMNS_BCA_PIPELINE", mode)
+        _, runs[mode] = predict_optimizing_macro_f1_score_using_bc(Y, 5, seed=3, tolerance=-1.0, max_iters=6,
+                                                                   bca_waves=64, return_meta=True,
+                                                                   bca_diagnostics=True)
+    a, b = runs["1"]["utilities"], runs["0"]["utilities"]
+    assert len(a) == len(b) == 6
+    assert np.abs(np.asarray(a) - np.asarray(b)).max() < PER_SWEEP_TOL
+    assert abs(a[-1] - b[-1]) < FINAL_TOL
+    assert runs["1"]["wavefronts"] == runs["0"]["wavefronts"] == [64] * 6

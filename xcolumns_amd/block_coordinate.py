@@ -15,8 +15,10 @@ Extra keyword arguments (all optional, swallowed by ``**kwargs`` in the
 reference's signature so call sites stay source-compatible):
 
 ``bca_waves``      number of wavefronts that walk the visiting order concurrently
-                   (1 = the reference's exact sequential sweep; default: about
-                   ``n / XCOLUMNS_BCA_STALE_DIV`` capped by what the GPU holds).
+                   (1 = the reference's exact sequential sweep; default: the
+                   staleness-budget policy, :class:`WavePolicy`).
+``bca_diagnostics`` True: ``meta`` also carries "wavefronts" and "rows_changed" per sweep
+                   (by default ``meta`` has exactly the reference's keys).
 ``order_backend``  "numpy" (default: the reference's RNG stream, generated on the
                    host and uploaded) or "device" (``torch.randperm`` on the GPU,
                    a different stream, no host work per sweep).
@@ -92,6 +94,19 @@ class WavePolicy:
         changed = self.n / 2 if changed_prev is None else max(1.0, changed_prev / self.world)
         want = int(self.budget * self.n * self.n / changed)
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
+
+
+    def device_params(self):
+        """(policy_num, world, min_waves, max_waves, fixed_waves) for xc_bca_pipeline_begin: the same
+        rule as :meth:`next`, evaluated by the boundary kernel."""
+        max_w = int(max(1, min(self.cap, self.n)))
+        fixed = int(max(1, min(self.fixed, self.n))) if self.fixed else 0
+        return self.budget * self.n * self.n, self.world, _MIN_WAVES, max_w, fixed
+
+    @property
+    def sequential(self) -> bool:
+        """bca_waves=1: the reference's exact sweep (one wavefront, host-paced)."""
+        return bool(self.fixed) and min(self.fixed, self.n) == 1
 
 
 def default_bca_waves(n_order: int) -> int:
@@ -290,6 +305,66 @@ class BcaCsrEngine:
         if full:
             self.orphans = None
 
+    # -- the sweep loop without a host round trip per iteration (include/xcolumns_amd.h) --------
+    def can_pipeline(self, n_order: int) -> bool:
+        return self.orphans is None and n_order >= self.csr.n and os.environ.get("XCOLUMNS_BCA_PIPELINE", "1") != "0"
+
+    def pipeline_begin(self, old_utility_sum: float, tolerance: float, divisor: float, maximize: bool,
+                       policy: "WavePolicy", first_waves: int):
+        """Arm the device-side stopping rule and wavefront policy."""
+        if getattr(self, "_ctrl", None) is None:
+            self._ctrl = torch.zeros(_lib.XC_CTRL_SIZE, dtype=torch.float64, device=self.dev)
+            ring = ctypes.c_void_p()
+            _lib.call("xc_host_alloc_pinned", ctypes.byref(ring), 4 * _lib.XC_CTRL_RING_SLOTS * 8)
+            self._ring_ptr = ring
+            self._ring = (ctypes.c_double * (4 * _lib.XC_CTRL_RING_SLOTS)).from_address(ring.value)
+            self._ring_events = []
+            for _ in range(_lib.XC_CTRL_RING_SLOTS):
+                ev = ctypes.c_void_p()
+                _lib.call("xc_event_create", ctypes.byref(ev))
+                self._ring_events.append(ev)
+        num, world, min_w, max_w, fixed = policy.device_params()
+        self._pipe_max_waves = max(2, max_w)
+        _lib.call("xc_bca_pipeline_begin", D.ptr(self._ctrl), float(old_utility_sum), float(tolerance), float(divisor),
+                  int(bool(maximize)), float(num), int(world), int(min_w), int(max_w), int(fixed),
+                  int(max(1, min(first_waves, max_w))), D.stream())
+
+    def pipeline_step(self, order: Optional[torch.Tensor], j: int, n_norm_utility: int):
+        """Enqueue sweep j and its boundary; returns at once.  The sweep runs only if the rule has
+        not fired at an earlier boundary."""
+        if self.packed is not None and self._pack_dirty:
+            self._repack()
+        use_packed = self.packed is not None
+        _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), int(use_packed),
+                  int(self._pipe_max_waves), D.ptr(self._ctrl), D.stream())
+        if self.comm is not None:
+            self.comm.all_reduce(self.acc)
+        slot = j % _lib.XC_CTRL_RING_SLOTS
+        _lib.call("xc_bca_plan_boundary_pipelined", self._plan_handle(), int(n_norm_utility), float(self.n_total),
+                  int(self.skip_tn), D.ptr(self._ctrl), slot, self._ring_ptr, self._ring_events[slot], D.stream())
+        self._acc_filled = False
+        self._partial_sweep = False
+
+    def pipeline_result(self, j: int):
+        """(utility sum, rows changed, wavefronts used, flag) of boundary j; flag 0 = continue,
+        1 = the stopping rule fired there, 2 = the step did not run.  Blocks until it is known."""
+        slot = j % _lib.XC_CTRL_RING_SLOTS
+        _lib.call("xc_event_synchronize", self._ring_events[slot])
+        r = self._ring
+        total, changed, waves, flag = r[4 * slot], r[4 * slot + 1], r[4 * slot + 2], r[4 * slot + 3]
+        if flag != 2.0:
+            self._changed_last = int(round(changed))
+        return total, int(round(changed)), int(waves), int(flag)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctrl", None) is not None:
+                for ev in self._ring_events:
+                    _lib.call("xc_event_destroy", ev)
+                _lib.call("xc_host_free_pinned", self._ring_ptr)
+        except Exception:
+            pass
+
     def reset_changed(self):
         """Kept for engine-interface compatibility: counters are reset by the kernels."""
         self._partial_sweep = False
@@ -351,7 +426,19 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
     changed_prev = None
     new_utility = None
     new_utility_sum = None
+    div = m if metric_aggregation == "mean" else 1
     for j in range(1, max_iters + 1):
+        if (not greedy and not getattr(policy, "sequential", True) and hasattr(eng, "can_pipeline")
+                and eng.can_pipeline(n_order)):
+            # every remaining sweep is a full concurrent one: hand the stopping rule to the GPU
+            if new_utility_sum is None:
+                if j == 1:
+                    eng.reset_state(False)
+                log_info("    Calculating expected confusion matrix ...", verbose)
+                new_utility_sum = eng.recompute_utility_sum(n_u)
+            _run_pipelined(eng, next_order, n_u, div, maximize, tolerance, max_iters, j, new_utility_sum,
+                           changed_prev, policy, verbose, meta)
+            return
         log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
         order = next_order()
         if j == 1:
@@ -370,7 +457,8 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
 
         log_info("    Doing block coordinate optimization steps ...", verbose)
         eng.reset_changed()
-        eng.sweep(order, n_order, policy.next(changed_prev), greedy=greedy)
+        n_waves = policy.next(changed_prev)
+        eng.sweep(order, n_order, n_waves, greedy=greedy)
         if greedy:
             eng.sync_column_sums()
         new_utility_sum = eng.recompute_utility_sum(n_u)
@@ -380,10 +468,42 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
         greedy = False
         meta["iters"] = j
         meta["utilities"].append(new_utility)
+        meta.setdefault("wavefronts", []).append(n_waves)
+        meta.setdefault("rows_changed", []).append(changed_prev)
         log_info(f"    Iteration {j}/{max_iters} finished, expected metric value: {old_utility} -> {new_utility}", verbose)
         if (maximize and new_utility - old_utility < tolerance) or (not maximize and new_utility - old_utility > tolerance):
             log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
             break
+
+
+def _run_pipelined(eng, next_order: Callable, n_u: int, div: float, maximize: bool, tolerance: float, max_iters: int,
+                   j0: int, old_sum: float, changed_prev, policy, verbose: bool, meta: Dict[str, Any]) -> None:
+    """Sweeps j0.. of the loop above with the stopping rule (block_coordinate.py:486-493) and the
+    wavefront policy evaluated on the GPU: sweep j + 1 is enqueued before the utility of sweep j has
+    reached the host; if the rule fired at boundary j it is a no-op.  Same utilities, same decision,
+    same prediction as the host-paced loop -- the GPU just never waits for Python."""
+    eng.pipeline_begin(old_sum, tolerance, div, maximize, policy, policy.next(changed_prev))
+    prev = [old_sum / div]
+
+    def collect(j) -> bool:
+        total, changed, waves, flag = eng.pipeline_result(j)
+        new_utility = total / div
+        meta["iters"] = j
+        meta["utilities"].append(new_utility)
+        meta.setdefault("wavefronts", []).append(waves)
+        meta.setdefault("rows_changed", []).append(changed)
+        log_info(f"    Iteration {j}/{max_iters} finished ({waves} wavefronts, {changed} rows changed), expected "
+                 f"metric value: {prev[0]} -> {new_utility}", verbose)
+        prev[0] = new_utility
+        if flag == 1:
+            log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
+        return flag == 1
+
+    for j in range(j0, max_iters + 1):
+        eng.pipeline_step(next_order(), j, n_u)
+        if j > j0 and collect(j - 1):
+            return
+    collect(max_iters)
 
 
 def _initial_csr_indices(y_proba: csr_matrix, init_y_pred, k: int, seed) -> Optional[np.ndarray]:
@@ -605,6 +725,7 @@ def predict_using_bc_with_0approx(
     n_u = n if normalize_conf_matrix else 1   # :403-405 (also the length of the visiting order, :414)
 
     bca_waves = kwargs.pop("bca_waves", None)
+    bca_diagnostics = kwargs.pop("bca_diagnostics", False)
     order_backend = kwargs.pop("order_backend", os.environ.get("XCOLUMNS_ORDER_BACKEND", "numpy"))
 
     if isinstance(y_proba, csr_matrix):
@@ -615,6 +736,9 @@ def predict_using_bc_with_0approx(
         y_pred = _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend)
 
+    if not bca_diagnostics:
+        meta.pop("wavefronts", None)
+        meta.pop("rows_changed", None)
     if return_meta:
         meta["time"] = time() - meta["time"]
         return y_pred, meta

@@ -70,6 +70,7 @@ struct SweepParams {
     int validate; // concurrent mode: re-read the records of the labels a row is about to change
     unsigned long long *changed;
     unsigned long long *stamps; // diagnostic builds only (-DXC_STAMPS): per-phase cycle sums
+    const double *ctrl;         // optional device-side loop control (XC_CTRL_*): stop flag and wave count
 };
 
 // In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with
@@ -142,12 +143,20 @@ template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACK
 __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
-    if (wave >= P.n_waves) return;
+    // device-side loop control (xc_bca_plan_*_pipelined): the previous boundary decided on
+    // the GPU whether this sweep runs at all and with how many wavefronts; the grid is
+    // launched for the largest count and the surplus waves leave here
+    int n_walk = P.n_waves;
+    if (P.ctrl) {
+        if (P.ctrl[XC_CTRL_STOP] != 0.0) return;
+        n_walk = (int)P.ctrl[XC_CTRL_WAVES];
+    }
+    if (wave >= n_walk) return;
     const int k = P.k;
     const double nn = P.nn;
     const bool greedy = P.greedy != 0;
     const bool skip_tn = P.skip_tn != 0;
-    const int64_t W = P.n_waves;
+    const int64_t W = n_walk;
     const int64_t last = P.n_order - 1;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.tpfp, 0, P.tpfp_bytes, XC_RSRC_WORD3);
     // float32 shadow of the records: only the concurrent (non-exact), non-greedy sweep reads it
@@ -612,8 +621,10 @@ __global__ __launch_bounds__(XC_BLOCK) void accumulate_pred_kernel(int64_t n_k, 
 __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, double nn, double n_counted,
                                                                   double *acc, int clear_acc, double *tpfp,
                                                                   float *shadow, const double *colsum,
-                                                                  xc_metric metric, int skip_tn, double *partials) {
+                                                                  xc_metric metric, int skip_tn, double *partials,
+                                                                  const double *ctrl) {
     __shared__ double red[XC_BLOCK];
+    if (ctrl && ctrl[XC_CTRL_STOP] != 0.0) return; // the loop has stopped: the sweep before was a no-op
     const int64_t per = (m + XC_UTILITY_PARTIALS - 1) / XC_UTILITY_PARTIALS;
     const int64_t j0 = (int64_t)blockIdx.x * per;
     const int64_t j1 = (j0 + per < m) ? j0 + per : m;
@@ -654,6 +665,68 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
         partials[XC_UTILITY_PARTIALS] = acc[2 * m];
         if (clear_acc) acc[2 * m] = 0.0;
     }
+}
+
+// ---- device-side sweep loop control -------------------------------------------------
+// The stopping rule of predict_using_bc_with_0approx (block_coordinate.py:486-493) and the
+// wavefront-count policy evaluated on the GPU, so the host can enqueue sweep j + 1 before it has
+// seen the utility of sweep j: a sweep launched after the rule fired is a no-op.
+__global__ void bca_ctrl_init_kernel(double *ctrl, double old_sum, double tolerance, double divisor, int maximize,
+                                     double policy_num, double world, double min_waves, double max_waves,
+                                     double fixed_waves, double first_waves) {
+    if (threadIdx.x != 0) return;
+    ctrl[XC_CTRL_STOP] = 0.0;
+    ctrl[XC_CTRL_OLD_SUM] = old_sum;
+    ctrl[XC_CTRL_WAVES] = first_waves;
+    ctrl[XC_CTRL_TOLERANCE] = tolerance;
+    ctrl[XC_CTRL_DIVISOR] = divisor;
+    ctrl[XC_CTRL_MAXIMIZE] = maximize ? 1.0 : 0.0;
+    ctrl[XC_CTRL_POLICY_NUM] = policy_num;
+    ctrl[XC_CTRL_WORLD] = world;
+    ctrl[XC_CTRL_MIN_WAVES] = min_waves;
+    ctrl[XC_CTRL_MAX_WAVES] = max_waves;
+    ctrl[XC_CTRL_FIXED_WAVES] = fixed_waves;
+}
+
+__global__ __launch_bounds__(XC_WAVE) void bca_boundary_finish_kernel(const double *partials, double *ctrl, int slot) {
+    __shared__ double s[XC_UTILITY_PARTIALS + 1];
+    if (ctrl[XC_CTRL_STOP] != 0.0) { // already stopped: report that this step did not run
+        if (threadIdx.x == 0) ctrl[XC_CTRL_RING + 4 * slot + 3] = 2.0;
+        return;
+    }
+    for (int i = threadIdx.x; i <= XC_UTILITY_PARTIALS; i += XC_WAVE) s[i] = partials[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double total = 0.0; // the order xc_utility_finish_host adds them in
+    for (int i = 0; i < XC_UTILITY_PARTIALS; ++i) total += s[i];
+    const double changed = s[XC_UTILITY_PARTIALS];
+    const double div = ctrl[XC_CTRL_DIVISOR];
+    const double new_u = total / div, old_u = ctrl[XC_CTRL_OLD_SUM] / div;
+    const double tol = ctrl[XC_CTRL_TOLERANCE];
+    const bool stop = ctrl[XC_CTRL_MAXIMIZE] != 0.0 ? (new_u - old_u < tol) : (new_u - old_u > tol); // :486-489
+    double *ring = ctrl + XC_CTRL_RING + 4 * slot;
+    ring[0] = total;
+    ring[1] = changed;
+    ring[2] = ctrl[XC_CTRL_WAVES]; // wavefronts the sweep before this boundary used
+    ring[3] = stop ? 1.0 : 0.0;
+    ctrl[XC_CTRL_OLD_SUM] = total;
+    ctrl[XC_CTRL_STOP] = stop ? 1.0 : 0.0;
+    // wavefronts of the next sweep: block_coordinate.WavePolicy.next
+    const double max_w = ctrl[XC_CTRL_MAX_WAVES];
+    double w;
+    if (ctrl[XC_CTRL_FIXED_WAVES] > 0.0) {
+        w = ctrl[XC_CTRL_FIXED_WAVES];
+    } else if (ctrl[XC_CTRL_WORLD] > 1.0) {
+        w = max_w;
+    } else {
+        double c = changed / ctrl[XC_CTRL_WORLD];
+        if (c < 1.0) c = 1.0;
+        w = floor(ctrl[XC_CTRL_POLICY_NUM] / c);
+        if (w < ctrl[XC_CTRL_MIN_WAVES]) w = ctrl[XC_CTRL_MIN_WAVES];
+    }
+    if (w > max_w) w = max_w;
+    if (w < 1.0) w = 1.0;
+    ctrl[XC_CTRL_WAVES] = w;
 }
 
 __global__ __launch_bounds__(XC_BLOCK) void utility_vectors_kernel(int64_t m, double nn, const double *stats,
@@ -832,17 +905,25 @@ int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices, const void 
     return XC_OK;
 }
 
-int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, double *acc, int clear_acc, double *tpfp,
-                          float *shadow, const double *colsum, const xc_metric *metric_host, int skip_tn,
-                          double *partials, void *stream) {
+static int commit_utility_impl(int64_t m, int64_t n_norm, double n_counted, double *acc, int clear_acc, double *tpfp,
+                               float *shadow, const double *colsum, const xc_metric *metric_host, int skip_tn,
+                               double *partials, const double *ctrl, void *stream) {
     if (m < 0 || n_norm < 1 || !tpfp || !colsum || !metric_host || !partials)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: bad argument");
     if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_commit_utility: unknown metric %d", metric_host->base);
     hipLaunchKernelGGL(xc::commit_utility_kernel, dim3(XC_UTILITY_PARTIALS), dim3(XC_BLOCK), 0, xc::as_stream(stream), m,
-                       (double)n_norm, n_counted, acc, clear_acc, tpfp, shadow, colsum, *metric_host, skip_tn, partials);
+                       (double)n_norm, n_counted, acc, clear_acc, tpfp, shadow, colsum, *metric_host, skip_tn, partials,
+                       ctrl);
     XC_CHECK_LAUNCH("commit_utility_kernel");
     return XC_OK;
+}
+
+int xc_bca_commit_utility(int64_t m, int64_t n_norm, double n_counted, double *acc, int clear_acc, double *tpfp,
+                          float *shadow, const double *colsum, const xc_metric *metric_host, int skip_tn,
+                          double *partials, void *stream) {
+    return commit_utility_impl(m, n_norm, n_counted, acc, clear_acc, tpfp, shadow, colsum, metric_host, skip_tn,
+                               partials, nullptr, stream);
 }
 
 int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats, const xc_metric *metric_host,
@@ -873,12 +954,12 @@ int xc_utility_finish_host(const double *partials, double *out_host, double *out
     return XC_OK;
 }
 
-int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
-                     const int32_t *indices, const void *data, int dtype, int max_row_nnz,
-                     int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
-                     int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
-                     double *acc, const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
-                     int64_t *changed, void *stream) {
+static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
+                          const int32_t *indices, const void *data, int dtype, int max_row_nnz,
+                          int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
+                          int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
+                          double *acc, const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
+                          int64_t *changed, const double *ctrl, void *stream) {
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
         !metric_host)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
@@ -905,18 +986,29 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
                                  static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
                                  static_cast<xc::uint4_t *>(packed), acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
-                                 reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
+                                 reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
                                   static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
                                   nullptr, acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                   (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
-                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer};
+                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
     }
     XC_CHECK_LAUNCH("bca_sweep_csr_kernel");
     return XC_OK;
+}
+
+int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
+                     const int32_t *indices, const void *data, int dtype, int max_row_nnz,
+                     int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
+                     int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
+                     double *acc, const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
+                     int64_t *changed, void *stream) {
+    return sweep_csr_impl(n_order, order, n_norm, indptr, indices, data, dtype, max_row_nnz, pred_indices, pred_eta,
+                          sel, orphans, k, m, tpfp, shadow, colsum, s_entry, packed, acc, metric_host, maximize, greedy,
+                          skip_tn, n_waves, changed, nullptr, stream);
 }
 
 // ---- measurement helpers (bench.py): HIP events owned by the library ---------------
@@ -1013,6 +1105,64 @@ int xc_bca_plan_boundary(void *plan, int64_t n_norm_utility, double n_counted, i
                                    p->colsum, &p->utility_metric, skip_tn, p->partials, stream);
     if (rc) return rc;
     return xc_utility_finish_host(p->partials, out_sum_host, out_extra_host, stream);
+}
+
+// ---- the sweep loop without a host round trip per iteration ---------------------------
+int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance, double divisor, int maximize,
+                          double policy_num, int world, int min_waves, int max_waves, int fixed_waves, int first_waves,
+                          void *stream) {
+    if (!ctrl || max_waves < 1 || first_waves < 1 || divisor <= 0.0)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_pipeline_begin: bad argument");
+    hipLaunchKernelGGL(xc::bca_ctrl_init_kernel, dim3(1), dim3(XC_WAVE), 0, xc::as_stream(stream), ctrl, old_utility_sum,
+                       tolerance, divisor, maximize, policy_num, (double)(world < 1 ? 1 : world), (double)min_waves,
+                       (double)max_waves, (double)fixed_waves, (double)first_waves);
+    XC_CHECK_LAUNCH("bca_ctrl_init_kernel");
+    return XC_OK;
+}
+
+int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed, int max_waves, const double *ctrl,
+                                void *stream) {
+    if (!plan || !ctrl || max_waves < 2)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep_pipelined: bad argument");
+    const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
+    return sweep_csr_impl(p->n, order, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
+                          p->pred_indices, p->pred_eta, p->sel, nullptr, p->k, p->m, p->tpfp, p->shadow, p->colsum,
+                          p->s_entry, use_packed ? p->packed : nullptr, p->acc, &p->gain_metric, p->maximize, 0,
+                          p->skip_tn, max_waves, nullptr, ctrl, stream);
+}
+
+int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_counted, int skip_tn, double *ctrl,
+                                   int slot, double *host_ring, void *event, void *stream) {
+    if (!plan || !ctrl || slot < 0 || slot >= XC_CTRL_RING_SLOTS || !host_ring)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_boundary_pipelined: bad argument");
+    const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
+    int rc = commit_utility_impl(p->m, n_norm_utility, n_counted, p->acc, 1, p->tpfp, p->shadow, p->colsum,
+                                 &p->utility_metric, skip_tn, p->partials, ctrl, stream);
+    if (rc) return rc;
+    hipStream_t st = xc::as_stream(stream);
+    hipLaunchKernelGGL(xc::bca_boundary_finish_kernel, dim3(1), dim3(XC_WAVE), 0, st, p->partials, ctrl, slot);
+    XC_CHECK_LAUNCH("bca_boundary_finish_kernel");
+    XC_HIP_TRY(hipMemcpyAsync(host_ring + 4 * slot, ctrl + XC_CTRL_RING + 4 * slot, 4 * sizeof(double),
+                              hipMemcpyDeviceToHost, st));
+    if (event) XC_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), st));
+    return XC_OK;
+}
+
+int xc_event_synchronize(void *event) {
+    if (!event) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_event_synchronize: NULL");
+    XC_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return XC_OK;
+}
+
+int xc_host_alloc_pinned(void **ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_host_alloc_pinned: bad argument");
+    XC_HIP_TRY(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+    return XC_OK;
+}
+
+int xc_host_free_pinned(void *ptr) {
+    if (ptr) XC_HIP_TRY(hipHostFree(ptr));
+    return XC_OK;
 }
 
 int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum, double n_counted, int skip_tn,
