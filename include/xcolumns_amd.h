@@ -326,8 +326,11 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
  * changed rows, wavefronts used, stop flag) one iteration late from a pinned ring.
  *
  * ctrl: float64[XC_CTRL_SIZE] on the device.  Ring slot s (s < XC_CTRL_RING_SLOTS) is
- * the four doubles at ctrl[XC_CTRL_RING + 4 s]: {utility sum, rows changed,
- * wavefronts of the sweep, 0 = continue | 1 = rule fired | 2 = step skipped}.
+ * XC_CTRL_RING_STRIDE doubles at ctrl[XC_CTRL_RING + XC_CTRL_RING_STRIDE s]: {utility sum,
+ * rows changed, wavefronts of the sweep, 0 = continue | 1 = rule fired | 2 = step
+ * skipped, sequence number (host ring only)}.  The host ring (pinned, host-mapped:
+ * xc_host_alloc_pinned of XC_CTRL_RING_STRIDE * XC_CTRL_RING_SLOTS doubles) has the
+ * same slots; the boundary kernel stores into it directly, sequence number last.
  * ------------------------------------------------------------------------- */
 #define XC_CTRL_STOP 0
 #define XC_CTRL_OLD_SUM 1
@@ -342,7 +345,8 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
 #define XC_CTRL_FIXED_WAVES 10
 #define XC_CTRL_RING 16
 #define XC_CTRL_RING_SLOTS 8
-#define XC_CTRL_SIZE (XC_CTRL_RING + 4 * XC_CTRL_RING_SLOTS)
+#define XC_CTRL_RING_STRIDE 8 /* doubles per slot: 4 results, the sequence number, padding */
+#define XC_CTRL_SIZE (XC_CTRL_RING + XC_CTRL_RING_STRIDE * XC_CTRL_RING_SLOTS)
 
 /* Arm the control block: `old_utility_sum` = utility sum of the current prediction;
  * the rule is (new/divisor - old/divisor < tolerance) for maximize, (> tolerance)
@@ -360,12 +364,17 @@ int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed
                                 const double *ctrl, void *stream);
 
 /* The boundary after it (the caller all-reduces acc in between when rows are
- * sharded): commit + utility partials, then the rule and the policy on the GPU,
- * the ring slot copied to host_ring[4 slot .. 4 slot + 3] (pinned) and `event`
- * recorded.  Nothing here blocks. */
+ * sharded): commit + utility partials, then the rule and the policy on the GPU; the
+ * results go to ring slot `slot` on the device and, stamped with `seq`, in the host
+ * ring.  Nothing here blocks, no copy and no event enter the stream. */
 int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_counted,
                                    int skip_tn, double *ctrl, int slot, double *host_ring,
-                                   void *event, void *stream);
+                                   double seq, void *stream);
+
+/* Wait (spinning) until host ring slot `slot` carries sequence number `seq`; fails if
+ * `stream` reports an error or drains without producing it, or after timeout_ms. */
+int xc_bca_ring_wait(const double *host_ring, int slot, double seq, double timeout_ms,
+                     void *stream);
 
 int xc_event_synchronize(void *event);
 int xc_host_alloc_pinned(void **ptr, int64_t bytes);

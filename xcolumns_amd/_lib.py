@@ -20,7 +20,8 @@ XC_F32, XC_F64 = 0, 1
 XC_MAX_K = 64
 XC_MAX_ROW_NNZ = 1024
 XC_UTILITY_PARTIALS = 1024
-XC_CTRL_RING, XC_CTRL_RING_SLOTS, XC_CTRL_SIZE = 16, 8, 16 + 4 * 8
+XC_CTRL_RING, XC_CTRL_RING_SLOTS, XC_CTRL_RING_STRIDE = 16, 8, 8
+XC_CTRL_SIZE = XC_CTRL_RING + XC_CTRL_RING_STRIDE * XC_CTRL_RING_SLOTS
 XC_ERR_BAD_ARG, XC_ERR_K_RANGE, XC_ERR_ROW_TOO_LONG, XC_ERR_NO_DEVICE = -1, -2, -3, -4
 
 # metric ids (include/xcolumns_amd.h)
@@ -67,7 +68,8 @@ SIGNATURES = {
                                       c_int, c_int, c_void_p]),
     "xc_bca_plan_sweep_pipelined": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "xc_bca_plan_boundary_pipelined": (c_int, [c_void_p, c_int64, c_double, c_int, c_void_p, c_int, c_void_p,
-                                               c_void_p, c_void_p]),
+                                               c_double, c_void_p]),
+    "xc_bca_ring_wait": (c_int, [c_void_p, c_int, c_double, c_double, c_void_p]),
     "xc_event_synchronize": (c_int, [c_void_p]),
     "xc_host_alloc_pinned": (c_int, [POINTER(c_void_p), c_int64]),
     "xc_host_free_pinned": (c_int, [c_void_p]),

@@ -314,15 +314,15 @@ class BcaCsrEngine:
         """Arm the device-side stopping rule and wavefront policy."""
         if getattr(self, "_ctrl", None) is None:
             self._ctrl = torch.zeros(_lib.XC_CTRL_SIZE, dtype=torch.float64, device=self.dev)
+            n_ring = _lib.XC_CTRL_RING_STRIDE * _lib.XC_CTRL_RING_SLOTS
             ring = ctypes.c_void_p()
-            _lib.call("xc_host_alloc_pinned", ctypes.byref(ring), 4 * _lib.XC_CTRL_RING_SLOTS * 8)
+            _lib.call("xc_host_alloc_pinned", ctypes.byref(ring), n_ring * 8)
             self._ring_ptr = ring
-            self._ring = (ctypes.c_double * (4 * _lib.XC_CTRL_RING_SLOTS)).from_address(ring.value)
-            self._ring_events = []
-            for _ in range(_lib.XC_CTRL_RING_SLOTS):
-                ev = ctypes.c_void_p()
-                _lib.call("xc_event_create", ctypes.byref(ev))
-                self._ring_events.append(ev)
+            self._ring = (ctypes.c_double * n_ring).from_address(ring.value)
+            for i in range(n_ring):
+                self._ring[i] = -1.0
+            self._pipe_seq = 0.0      # grows by one per boundary over the engine's lifetime
+            self._seq_of = {}
         num, world, min_w, max_w, fixed = policy.device_params()
         self._pipe_max_waves = max(2, max_w)
         _lib.call("xc_bca_pipeline_begin", D.ptr(self._ctrl), float(old_utility_sum), float(tolerance), float(divisor),
@@ -340,8 +340,10 @@ class BcaCsrEngine:
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
         slot = j % _lib.XC_CTRL_RING_SLOTS
+        self._pipe_seq += 1.0
+        self._seq_of[slot] = self._pipe_seq
         _lib.call("xc_bca_plan_boundary_pipelined", self._plan_handle(), int(n_norm_utility), float(self.n_total),
-                  int(self.skip_tn), D.ptr(self._ctrl), slot, self._ring_ptr, self._ring_events[slot], D.stream())
+                  int(self.skip_tn), D.ptr(self._ctrl), slot, self._ring_ptr, self._pipe_seq, D.stream())
         self._acc_filled = False
         self._partial_sweep = False
 
@@ -349,9 +351,9 @@ class BcaCsrEngine:
         """(utility sum, rows changed, wavefronts used, flag) of boundary j; flag 0 = continue,
         1 = the stopping rule fired there, 2 = the step did not run.  Blocks until it is known."""
         slot = j % _lib.XC_CTRL_RING_SLOTS
-        _lib.call("xc_event_synchronize", self._ring_events[slot])
-        r = self._ring
-        total, changed, waves, flag = r[4 * slot], r[4 * slot + 1], r[4 * slot + 2], r[4 * slot + 3]
+        _lib.call("xc_bca_ring_wait", self._ring_ptr, slot, self._seq_of[slot], 600000.0, D.stream())
+        r, o = self._ring, _lib.XC_CTRL_RING_STRIDE * slot
+        total, changed, waves, flag = r[o], r[o + 1], r[o + 2], r[o + 3]
         if flag != 2.0:
             self._changed_last = int(round(changed))
         return total, int(round(changed)), int(waves), int(flag)
@@ -359,8 +361,7 @@ class BcaCsrEngine:
     def __del__(self):
         try:
             if getattr(self, "_ctrl", None) is not None:
-                for ev in self._ring_events:
-                    _lib.call("xc_event_destroy", ev)
+                torch.cuda.synchronize()
                 _lib.call("xc_host_free_pinned", self._ring_ptr)
         except Exception:
             pass

@@ -30,6 +30,9 @@
 // tests); the driver picks n_waves as a small fraction of n.
 #include <hip/hip_ext.h>
 
+#include <atomic>
+#include <chrono>
+
 #include "xc_common.h"
 #include "xc_host.h"
 
@@ -688,27 +691,53 @@ __global__ void bca_ctrl_init_kernel(double *ctrl, double old_sum, double tolera
     ctrl[XC_CTRL_FIXED_WAVES] = fixed_waves;
 }
 
-__global__ __launch_bounds__(XC_WAVE) void bca_boundary_finish_kernel(const double *partials, double *ctrl, int slot) {
-    __shared__ double s[XC_UTILITY_PARTIALS + 1];
+// The order every sum of the XC_UTILITY_PARTIALS partials uses, on the GPU and on the host
+// (xc_utility_finish_host): a fixed pairwise tree, s[i] += s[i + stride] for stride = 512 .. 1.
+__global__ __launch_bounds__(XC_UTILITY_PARTIALS / 2) void bca_boundary_finish_kernel(const double *partials,
+                                                                                    double *ctrl, int slot,
+                                                                                    double *host_ring, double seq) {
+    __shared__ double s[XC_UTILITY_PARTIALS];
+    double *ring = ctrl + XC_CTRL_RING + XC_CTRL_RING_STRIDE * slot;
+    volatile double *hring = host_ring ? host_ring + XC_CTRL_RING_STRIDE * slot : nullptr;
     if (ctrl[XC_CTRL_STOP] != 0.0) { // already stopped: report that this step did not run
-        if (threadIdx.x == 0) ctrl[XC_CTRL_RING + 4 * slot + 3] = 2.0;
+        if (threadIdx.x == 0) {
+            ring[3] = 2.0;
+            if (hring) {
+                hring[3] = 2.0;
+                __threadfence_system();
+                hring[4] = seq;
+            }
+        }
         return;
     }
-    for (int i = threadIdx.x; i <= XC_UTILITY_PARTIALS; i += XC_WAVE) s[i] = partials[i];
+    const int t = threadIdx.x;
+    s[t] = partials[t];
+    s[t + XC_UTILITY_PARTIALS / 2] = partials[t + XC_UTILITY_PARTIALS / 2];
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double total = 0.0; // the order xc_utility_finish_host adds them in
-    for (int i = 0; i < XC_UTILITY_PARTIALS; ++i) total += s[i];
-    const double changed = s[XC_UTILITY_PARTIALS];
+    for (int stride = XC_UTILITY_PARTIALS / 2; stride > 0; stride >>= 1) {
+        if (t < stride) s[t] += s[t + stride];
+        __syncthreads();
+    }
+    if (t != 0) return;
+    const double total = s[0];
+    const double changed = partials[XC_UTILITY_PARTIALS];
     const double div = ctrl[XC_CTRL_DIVISOR];
     const double new_u = total / div, old_u = ctrl[XC_CTRL_OLD_SUM] / div;
     const double tol = ctrl[XC_CTRL_TOLERANCE];
     const bool stop = ctrl[XC_CTRL_MAXIMIZE] != 0.0 ? (new_u - old_u < tol) : (new_u - old_u > tol); // :486-489
-    double *ring = ctrl + XC_CTRL_RING + 4 * slot;
+    const double used = ctrl[XC_CTRL_WAVES]; // wavefronts the sweep before this boundary used
     ring[0] = total;
     ring[1] = changed;
-    ring[2] = ctrl[XC_CTRL_WAVES]; // wavefronts the sweep before this boundary used
+    ring[2] = used;
     ring[3] = stop ? 1.0 : 0.0;
+    if (hring) { // straight into the host's pinned ring: no copy engine, no event in the stream
+        hring[0] = total;
+        hring[1] = changed;
+        hring[2] = used;
+        hring[3] = stop ? 1.0 : 0.0;
+        __threadfence_system();
+        hring[4] = seq;
+    }
     ctrl[XC_CTRL_OLD_SUM] = total;
     ctrl[XC_CTRL_STOP] = stop ? 1.0 : 0.0;
     // wavefronts of the next sweep: block_coordinate.WavePolicy.next
@@ -947,9 +976,10 @@ int xc_utility_finish_host(const double *partials, double *out_host, double *out
     hipStream_t st = xc::as_stream(stream);
     XC_HIP_TRY(hipMemcpyAsync(buf, partials, sizeof(double) * (XC_UTILITY_PARTIALS + 1), hipMemcpyDeviceToHost, st));
     XC_HIP_TRY(hipStreamSynchronize(st));
-    double sum = 0.0;
-    for (int i = 0; i < XC_UTILITY_PARTIALS; ++i) sum += buf[i];
-    *out_host = sum;
+    // the fixed pairwise tree bca_boundary_finish_kernel uses, so both give the same bits
+    for (int stride = XC_UTILITY_PARTIALS / 2; stride > 0; stride >>= 1)
+        for (int i = 0; i < stride; ++i) buf[i] += buf[i + stride];
+    *out_host = buf[0];
     if (out_extra_host) *out_extra_host = buf[XC_UTILITY_PARTIALS];
     return XC_OK;
 }
@@ -1132,19 +1162,39 @@ int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed
 }
 
 int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_counted, int skip_tn, double *ctrl,
-                                   int slot, double *host_ring, void *event, void *stream) {
-    if (!plan || !ctrl || slot < 0 || slot >= XC_CTRL_RING_SLOTS || !host_ring)
+                                   int slot, double *host_ring, double seq, void *stream) {
+    if (!plan || !ctrl || slot < 0 || slot >= XC_CTRL_RING_SLOTS)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_boundary_pipelined: bad argument");
     const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
     int rc = commit_utility_impl(p->m, n_norm_utility, n_counted, p->acc, 1, p->tpfp, p->shadow, p->colsum,
                                  &p->utility_metric, skip_tn, p->partials, ctrl, stream);
     if (rc) return rc;
-    hipStream_t st = xc::as_stream(stream);
-    hipLaunchKernelGGL(xc::bca_boundary_finish_kernel, dim3(1), dim3(XC_WAVE), 0, st, p->partials, ctrl, slot);
+    hipLaunchKernelGGL(xc::bca_boundary_finish_kernel, dim3(1), dim3(XC_UTILITY_PARTIALS / 2), 0, xc::as_stream(stream),
+                       p->partials, ctrl, slot, host_ring, seq);
     XC_CHECK_LAUNCH("bca_boundary_finish_kernel");
-    XC_HIP_TRY(hipMemcpyAsync(host_ring + 4 * slot, ctrl + XC_CTRL_RING + 4 * slot, 4 * sizeof(double),
-                              hipMemcpyDeviceToHost, st));
-    if (event) XC_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), st));
+    return XC_OK;
+}
+
+// Spin (GIL-free under ctypes) until ring slot `slot` of the pinned host ring carries sequence
+// number `seq`; XC_ERR_BAD_ARG after timeout_ms without it (a stuck stream, not a slow one).
+int xc_bca_ring_wait(const double *host_ring, int slot, double seq, double timeout_ms, void *stream) {
+    if (!host_ring || slot < 0 || slot >= XC_CTRL_RING_SLOTS)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_ring_wait: bad argument");
+    const volatile double *r = host_ring + XC_CTRL_RING_STRIDE * slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (r[4] != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFu) == 0) { // about once a millisecond: is the stream still alive?
+            const hipError_t q = hipStreamQuery(xc::as_stream(stream));
+            if (q != hipSuccess && q != hipErrorNotReady) return xc::fail_hip(q, "xc_bca_ring_wait: stream");
+            if (q == hipSuccess && r[4] != seq)
+                return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_ring_wait: the stream drained without boundary %.0f", seq);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > timeout_ms) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_ring_wait: no result after %.0f ms", timeout_ms);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return XC_OK;
 }
 
