@@ -158,9 +158,12 @@ int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_p
 
 /* ---- block coordinate ascent, CSR ------------------------------------- */
 
-/* packed[p] <- {indices[p] | sel[p] << 31, data[p], s_entry[p]} for float32 scores. */
+/* packed[p] <- {indices[p] | hot_slot[indices[p]] << 25 | sel[p] << 31, data[p], s_entry[p]}
+ * for float32 scores (column ids < 2^25).  hot_slot: optional uint8[m], 1..63 for the
+ * labels whose deltas a sweeping wave batches (see xc_bca_sweep_csr `hot_labels`), 0 else. */
 int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data,
-                     const uint8_t *sel, const double *s_entry, void *packed, void *stream);
+                     const uint8_t *sel, const double *s_entry, const uint8_t *hot_slot,
+                     void *packed, void *stream);
 
 /* For a prediction given as column ids (pred_indices[n*k], k per row), look up
  * each id in its row of y_proba: pred_eta[n*k] <- the stored value, or 0 when the
@@ -231,6 +234,11 @@ int xc_utility_finish_host(const double *partials, double *out_host,
  *                greedy (colsum is then gathered and grows during the sweep)
  *   packed       optional packed row stream (float32 scores, non-greedy); NULL = read
  *                indices / data / sel / s_entry separately
+ *   hot_labels   optional int32[64] (with packed, shadow and acc): label id of hot slot
+ *                h = 1..63 (-1 = unused; entry 0 unused).  A wave sums its deltas to these
+ *                labels in LDS and publishes them every few rows as one atomic per label
+ *                (same-address float atomics serialise at ~11 ns); they are exempt from
+ *                the optimistic validation
  *   acc          optional float64[2m + 1], zeroed by the caller: the sweep adds every
  *                visited row's NEW prediction into it ({tp, fp} per label) -- when
  *                all rows are visited this IS the sweep-boundary recompute
@@ -251,8 +259,8 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm,
                      int dtype, int max_row_nnz, int32_t *pred_indices,
                      void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
                      int64_t m, double *tpfp, float *shadow, double *colsum,
-                     const double *s_entry, void *packed, double *acc,
-                     const xc_metric *metric_host, int maximize, int greedy,
+                     const double *s_entry, void *packed, const int32_t *hot_labels,
+                     double *acc, const xc_metric *metric_host, int maximize, int greedy,
                      int skip_tn, int n_waves, int64_t *changed, void *stream);
 
 /* Plan: bind the per-run constants of a CSR BCA once; afterwards a sweep and its boundary
@@ -263,8 +271,9 @@ int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total,
                        const int32_t *indptr, const int32_t *indices, const void *data,
                        int dtype, int max_row_nnz, int k, int32_t *pred_indices,
                        void *pred_eta, uint8_t *sel, double *tpfp, float *shadow,
-                       double *colsum, const double *s_entry, void *packed, double *acc,
-                       double *partials, const xc_metric *gain_metric,
+                       double *colsum, const double *s_entry, void *packed,
+                       const int32_t *hot_labels, double *acc, double *partials,
+                       const xc_metric *gain_metric,
                        const xc_metric *utility_metric, int maximize, int skip_tn);
 int xc_bca_plan_destroy(void *plan);
 /* with_acc: accumulate the new prediction into acc (pass 1 when every row is visited) */

@@ -82,18 +82,19 @@ SIGNATURES = {
                                                c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "xc_threshold_fill_csr_rowwise": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p,
                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "xc_bca_pack_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xc_bca_pack_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_accumulate_pred": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_commit_utility": (c_int, [c_int64, c_int64, c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       POINTER(XcMetric), c_int, c_void_p, c_void_p]),
     "xc_utility_finish_host": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), c_void_p]),
     "xc_bca_sweep_csr": (c_int, [c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(XcMetric),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(XcMetric),
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xc_bca_plan_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, POINTER(XcMetric), POINTER(XcMetric), c_int, c_int]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, POINTER(XcMetric), POINTER(XcMetric), c_int,
+                                   c_int]),
     "xc_bca_plan_destroy": (c_int, [c_void_p]),
     "xc_bca_plan_sweep": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p]),

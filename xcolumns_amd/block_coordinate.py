@@ -155,9 +155,25 @@ class BcaCsrEngine:
         # float32 scores: indices / data / sel / s_entry interleaved in 16-byte entries, so a
         # candidate streams in as one 16-byte lane load (XCOLUMNS_BCA_PACKED=0 disables)
         self.packed = (torch.empty((max(1, csr.nnz), 4), dtype=torch.int32, device=dev)
-                       if csr.data.dtype == torch.float32 and os.environ.get("XCOLUMNS_BCA_PACKED", "1") != "0"
-                       else None)
+                       if csr.data.dtype == torch.float32 and m <= (1 << 25)
+                       and os.environ.get("XCOLUMNS_BCA_PACKED", "1") != "0" else None)
         self._pack_dirty = True
+        # Hot labels (the head of a skewed popularity): stored in >= n/32 rows, at most 63 of them.
+        # A sweeping wave batches its deltas to them (xc_bca_sweep_csr `hot_labels`);
+        # XCOLUMNS_BCA_HOT=0 disables.  Uniform popularity has none.
+        self.hot_slot = self.hot_labels = None
+        if (self.packed is not None and self.shadow is not None and csr.nnz > 0
+                and os.environ.get("XCOLUMNS_BCA_HOT", "1") != "0"):
+            counts = torch.bincount(csr.indices, minlength=m)
+            top = torch.topk(counts, min(63, m))
+            keep = top.values >= max(512, csr.n // 32)
+            n_hot = int(keep.sum().item())
+            if n_hot > 0:
+                labels = top.indices[:n_hot].to(torch.int32)
+                self.hot_labels = torch.full((64,), -1, dtype=torch.int32, device=dev)
+                self.hot_labels[1:n_hot + 1] = labels
+                self.hot_slot = torch.zeros(m, dtype=torch.uint8, device=dev)
+                self.hot_slot[labels.long()] = torch.arange(1, n_hot + 1, dtype=torch.uint8, device=dev)
         # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count
         self.acc = torch.zeros(2 * m + 1, dtype=torch.float64, device=dev)
         self._acc_filled = False    # did the last sweep leave the new prediction's statistics in acc
@@ -202,7 +218,7 @@ class BcaCsrEngine:
             _lib.call("xc_bca_plan_create", ctypes.byref(h), c.n, c.m, self.n_total, D.ptr(c.indptr), D.ptr(c.indices),
                       D.ptr(c.data), c.code, int(c.max_row_nnz), self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
                       D.ptr(self.sel), D.ptr(self.tpfp), D.ptr(self.shadow), D.ptr(self.colsum), D.ptr(self.s_entry),
-                      D.ptr(self.packed), D.ptr(self.acc), D.ptr(self.partials), ctypes.byref(self.gain_metric),
+                      D.ptr(self.packed), D.ptr(self.hot_labels), D.ptr(self.acc), D.ptr(self.partials), ctypes.byref(self.gain_metric),
                       ctypes.byref(self.utility_metric), int(self.maximize), int(self.skip_tn))
             self._plan, self._plan_key = h, key
         return self._plan
@@ -244,7 +260,7 @@ class BcaCsrEngine:
     def _repack(self):
         c = self.csr
         _lib.call("xc_bca_pack_rows", c.nnz, D.ptr(c.indices), D.ptr(c.data), D.ptr(self.sel), D.ptr(self.s_entry),
-                  D.ptr(self.packed), D.stream())
+                  D.ptr(self.hot_slot), D.ptr(self.packed), D.stream())
         self._pack_dirty = False
 
     def sync_column_sums(self):

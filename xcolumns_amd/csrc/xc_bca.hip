@@ -59,6 +59,7 @@ struct SweepParams {
     const double *s_entry;  // [nnz] colsum expanded per stored entry (NULL in the greedy sweep)
     uint4_t *packed;        // optional [nnz] 16-byte entries {col | sel << 31, eta (f32), s (f64)}: the
                             // row streams interleaved so a candidate is ONE 16-byte lane load
+    const int32_t *hot_labels; // optional [64] (with packed): label id of hot slot h = 1..63, -1 = unused
     double *acc;            // optional [2m + 1]: from-scratch {tp, fp} of the NEW prediction, [2m] += changed rows
     int64_t m;
     unsigned tpfp_bytes;
@@ -104,12 +105,18 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 #define XC_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
 #define XC_CPOL_SC1 16           /* cache policy bit 4 = sc1 on gfx94x/gfx950 */
 #define XC_MAX_RETRY 3           /* optimistic validation: re-score a row at most this often */
+/* packed entry word 0: column id (25 bits) | hot slot (6 bits) | sel (1 bit) */
+#define XC_PACK_COL_MASK 0x01ffffffu
+#define XC_PACK_HOT_SHIFT 25
+#define XC_PACK_HOT_MASK 63u
+#define XC_HOT_FLUSH_ROWS 8      /* a wave publishes its hot-label deltas every this many rows */
 
 template <typename T, int CH>
 struct RowData {
     int idx[CH];
     T eta[CH];
     uint8_t sel[CH]; // is the entry in the row's current prediction
+    uint8_t hot[CH]; // packed stream only: hot slot 1..63 of the entry's label, 0 = none
     double sc[CH];   // column sum of the entry's label (s_entry), non-greedy sweeps
 };
 
@@ -127,7 +134,8 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
         if (PACKED) {
             // one 16-byte load per lane = 1 KiB per wave instruction, the widest shape
             const uint4_t w = __builtin_nontemporal_load(P.packed + s + pc);
-            d.idx[c] = (int)(w.x & 0x7fffffffu);
+            d.idx[c] = (int)(w.x & XC_PACK_COL_MASK);
+            d.hot[c] = (uint8_t)((w.x >> XC_PACK_HOT_SHIFT) & XC_PACK_HOT_MASK);
             d.sel[c] = (uint8_t)(w.x >> 31);
             d.eta[c] = (T)__uint_as_float(w.y);
             d.sc[c] = __longlong_as_double((long long)(((unsigned long long)w.w << 32) | w.z));
@@ -135,6 +143,7 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
             d.idx[c] = __builtin_nontemporal_load(P.indices + s + pc);
             d.eta[c] = __builtin_nontemporal_load(P.data + s + pc);
             d.sel[c] = __builtin_nontemporal_load(P.sel + s + pc);
+            d.hot[c] = 0;
             d.sc[c] = P.s_entry ? __builtin_nontemporal_load(P.s_entry + s + pc) : 0.0;
         }
     }
@@ -142,10 +151,22 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
 
 // SHADOW (only with !EXACT, never greedy): gather the float32 copy of the records.
 // PACKED (float32 scores, never greedy): the row streams come interleaved from `packed`.
-template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED>
+// HOT (with SHADOW, PACKED and acc): deltas to the hot labels are batched per workgroup.
+template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
 __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    // hot-label delta table of the workgroup (see flush_hot below): zeroed before any wave leaves
+    __shared__ float s_hot[XC_WAVE][2];
+    __shared__ int s_hot_ticks, s_hot_done;
+    if (HOT) {
+        if (threadIdx.x < XC_WAVE) {
+            s_hot[threadIdx.x][0] = 0.0f;
+            s_hot[threadIdx.x][1] = 0.0f;
+        }
+        if (threadIdx.x == 0) s_hot_ticks = s_hot_done = 0;
+        __syncthreads();
+    }
     // device-side loop control (xc_bca_plan_*_pipelined): the previous boundary decided on
     // the GPU whether this sweep runs at all and with how many wavefronts; the grid is
     // launched for the largest count and the surplus waves leave here
@@ -203,9 +224,34 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     double pend_val = 0.0; // eta (even lane) or 1 - eta (odd lane)
     int pend_n = 0;
     auto flush_pending = [&]() {
+#ifndef XC_EXP_SKIP_ACC /* diagnostic builds only (tools/build_exp.sh): what does this traffic cost? */
         if (lane < 2 * pend_n) atomic_add_f64(P.acc + (int64_t)pend_idx * 2 + (lane & 1), pend_val);
+#endif
     };
-
+    // Hot labels (the head of a Zipf-like popularity): in the first sweeps nearly every row
+    // changes them, and float atomics on ONE address run one after the other at the memory side
+    // (11-35 ns each: 1.8 ms of a 2.7 ms sweep at C2-Zipf).  The waves of a workgroup therefore
+    // sum their deltas to the (at most 63) hot labels in an LDS table -- slot h = lane h at flush
+    // time -- and the workgroup publishes it about every XC_HOT_FLUSH_ROWS rows per wave as one
+    // atomic per label.  Their statistics are sums over thousands of rows, so a few rows' delay
+    // moves a gain by a relative 1e-3 at most; for the same reason hot labels are left out of the
+    // optimistic validation (their records move all the time).
+    constexpr bool hot_on = HOT;
+    const int my_hot_label = hot_on ? P.hot_labels[lane] : -1;
+    const int waves_here = (int)((n_walk - (int64_t)blockIdx.x * (XC_BLOCK / XC_WAVE)) < (XC_BLOCK / XC_WAVE)
+                                     ? (n_walk - (int64_t)blockIdx.x * (XC_BLOCK / XC_WAVE))
+                                     : (XC_BLOCK / XC_WAVE));
+    int hot_rows = 0;
+    auto flush_hot = [&]() { // whoever exchanges a non-zero sum out of the table publishes it
+        if (my_hot_label >= 0) {
+            const float a = __hip_atomic_exchange(&s_hot[lane][0], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const float b = __hip_atomic_exchange(&s_hot[lane][1], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef XC_EXP_SKIP_HOT
+            if (a != 0.0f) atomic_add_f32(P.shadow + (int64_t)my_hot_label * 2, a);
+            if (b != 0.0f) atomic_add_f32(P.shadow + (int64_t)my_hot_label * 2 + 1, b);
+#endif
+        }
+    };
     XC_STAMP_DECL;
     XC_STAMP_START();
     for (; pos < P.n_order; pos += W) {
@@ -426,7 +472,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         bool moved = false;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            if (in_new[c] != in_old[c]) {
+            if (in_new[c] != in_old[c] && !(hot_on && cur.hot[c] != 0)) {
                 if (SHADOW) {
                     const float2_t now = __builtin_bit_cast(
                         float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
@@ -491,7 +537,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                     P.sel[s0 + lane + XC_WAVE * c] = in_new[c] ? 1 : 0;
                     if (PACKED)
                         reinterpret_cast<unsigned *>(P.packed + s0 + lane + XC_WAVE * c)[0] =
-                            (unsigned)cur.idx[c] | (in_new[c] ? 0x80000000u : 0u);
+                            (unsigned)cur.idx[c] | ((unsigned)cur.hot[c] << XC_PACK_HOT_SHIFT) |
+                            (in_new[c] ? 0x80000000u : 0u);
                 }
                 if (lane + XC_WAVE * c < r) {
                     double *st = P.tpfp + (int64_t)cur.idx[c] * 2;
@@ -512,15 +559,29 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                             atomic_add_f64(st + 0, sgn * ed);
                             atomic_add_f64(st + 1, sgn * omd);
                         }
-                        if (P.shadow) { // keep the float32 copy in step
+                        if (hot_on && cur.hot[c] != 0) { // summed per workgroup, published by flush_hot
+                            (void)__hip_atomic_fetch_add(&s_hot[cur.hot[c]][0], (float)(sgn * ed), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                            (void)__hip_atomic_fetch_add(&s_hot[cur.hot[c]][1], (float)(sgn * omd), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else if (P.shadow) { // keep the float32 copy in step
+#ifndef XC_EXP_SKIP_DELTA
                             float *sh = P.shadow + (int64_t)cur.idx[c] * 2;
                             atomic_add_f32(sh + 0, (float)(sgn * ed));
                             atomic_add_f32(sh + 1, (float)(sgn * omd));
+#endif
                         }
                     }
                 }
             }
             if (row_changed) ++n_changed;
+        }
+        if (hot_on && ++hot_rows >= XC_HOT_FLUSH_ROWS) { // one publication per round of the workgroup's waves
+            hot_rows = 0;
+            int tick = 0;
+            if (lane == 0) tick = __hip_atomic_fetch_add(&s_hot_ticks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tick = __builtin_amdgcn_readfirstlane(tick);
+            if ((tick + 1) % waves_here == 0) flush_hot();
         }
 
         // sequential mode: this wave's atomics must have been performed before it
@@ -541,6 +602,11 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         XC_STAMP(5); // prefetch landing
     }
     if (P.acc) flush_pending();
+    if (hot_on) { // the last wave of the workgroup to finish publishes what is left
+        int done = 0;
+        if (lane == 0) done = __hip_atomic_fetch_add(&s_hot_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(done) == waves_here - 1) flush_hot();
+    }
 #ifdef XC_STAMPS
     if (P.stamps && lane == 0)
         for (int i = 0; i < XC_NSTAMP; ++i) atomicAdd(P.stamps + i, st_sum[i]);
@@ -591,12 +657,15 @@ __global__ __launch_bounds__(XC_BLOCK) void expand_colsum_kernel(int64_t nnz, co
 
 // packed[p] = {col | sel << 31, eta, s}: the four row streams of a float32 matrix interleaved
 __global__ __launch_bounds__(XC_BLOCK) void pack_rows_kernel(int64_t nnz, const int32_t *indices, const float *data,
-                                                             const uint8_t *sel, const double *s_entry, uint4_t *packed) {
+                                                             const uint8_t *sel, const double *s_entry,
+                                                             const uint8_t *hot_slot, uint4_t *packed) {
     const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride) {
         const unsigned long long sb = (unsigned long long)__double_as_longlong(s_entry[t]);
         uint4_t w;
-        w.x = (unsigned)indices[t] | (sel[t] ? 0x80000000u : 0u);
+        const unsigned col = (unsigned)indices[t];
+        w.x = col | ((hot_slot ? (unsigned)hot_slot[col] & XC_PACK_HOT_MASK : 0u) << XC_PACK_HOT_SHIFT) |
+              (sel[t] ? 0x80000000u : 0u);
         w.y = __float_as_uint(data[t]);
         w.z = (unsigned)sb;
         w.w = (unsigned)(sb >> 32);
@@ -792,44 +861,47 @@ static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stam
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_validate = 1;                           // xc_bca_set_validation
 
-template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED>
+template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
 static void launch_sweep_one(const SweepParams<T> &P, hipStream_t st) {
     const int blocks = (P.n_waves + 3) / 4;
     if (g_ev_start && g_ev_stop) {
         // start / stop events attached to the dispatch itself: the measured span is the
         // kernel, not the kernel plus the dispatch gap an event pair around it would add
-        hipExtLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED>), dim3(blocks),
+        hipExtLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>), dim3(blocks),
                               dim3(XC_BLOCK), 0, st, g_ev_start, g_ev_stop, 0, P);
         g_ev_start = g_ev_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED>), dim3(blocks), dim3(XC_BLOCK),
-                           0, st, P);
+        hipLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>), dim3(blocks),
+                           dim3(XC_BLOCK), 0, st, P);
     }
 }
 
-template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED>
+template <typename T, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
 static void launch_sweep_impl(const SweepParams<T> &P, int ch, hipStream_t st) {
     switch (ch) {
-    case 1: launch_sweep_one<T, 1, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
-    case 2: launch_sweep_one<T, 2, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
-    case 4: launch_sweep_one<T, 4, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
-    case 8: launch_sweep_one<T, 8, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
-    default: launch_sweep_one<T, 16, EXACT, HAS_ORDER, SHADOW, PACKED>(P, st); break;
+    case 1: launch_sweep_one<T, 1, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>(P, st); break;
+    case 2: launch_sweep_one<T, 2, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>(P, st); break;
+    case 4: launch_sweep_one<T, 4, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>(P, st); break;
+    case 8: launch_sweep_one<T, 8, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>(P, st); break;
+    default: launch_sweep_one<T, 16, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>(P, st); break;
     }
 }
 
 template <typename T, bool PACKED>
 static void launch_sweep_mode(const SweepParams<T> &P, int ch, hipStream_t st) {
-    const bool exact = P.n_waves == 1;
+    const bool exact = P.n_waves == 1 && !P.ctrl;
     const bool shadow = !exact && !P.greedy && P.shadow != nullptr;
+    const bool hot = PACKED && shadow && P.hot_labels != nullptr && P.acc != nullptr;
     if (P.order) {
-        if (exact) launch_sweep_impl<T, true, true, false, PACKED>(P, ch, st);
-        else if (shadow) launch_sweep_impl<T, false, true, true, PACKED>(P, ch, st);
-        else launch_sweep_impl<T, false, true, false, PACKED>(P, ch, st);
+        if (exact) launch_sweep_impl<T, true, true, false, PACKED, false>(P, ch, st);
+        else if (hot) launch_sweep_impl<T, false, true, true, PACKED, PACKED>(P, ch, st);
+        else if (shadow) launch_sweep_impl<T, false, true, true, PACKED, false>(P, ch, st);
+        else launch_sweep_impl<T, false, true, false, PACKED, false>(P, ch, st);
     } else {
-        if (exact) launch_sweep_impl<T, true, false, false, PACKED>(P, ch, st);
-        else if (shadow) launch_sweep_impl<T, false, false, true, PACKED>(P, ch, st);
-        else launch_sweep_impl<T, false, false, false, PACKED>(P, ch, st);
+        if (exact) launch_sweep_impl<T, true, false, false, PACKED, false>(P, ch, st);
+        else if (hot) launch_sweep_impl<T, false, false, true, PACKED, PACKED>(P, ch, st);
+        else if (shadow) launch_sweep_impl<T, false, false, true, PACKED, false>(P, ch, st);
+        else launch_sweep_impl<T, false, false, false, PACKED, false>(P, ch, st);
     }
 }
 
@@ -906,12 +978,12 @@ int xc_bca_expand_colsum(int64_t nnz, const int32_t *indices, const double *cols
 }
 
 int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data, const uint8_t *sel,
-                     const double *s_entry, void *packed, void *stream) {
+                     const double *s_entry, const uint8_t *hot_slot, void *packed, void *stream) {
     if (nnz < 0 || (nnz > 0 && (!indices || !data || !sel || !s_entry || !packed)))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_pack_rows: bad argument");
     if (nnz == 0) return XC_OK;
     hipLaunchKernelGGL(xc::pack_rows_kernel, dim3(xc::grid_for(nnz)), dim3(XC_BLOCK), 0, xc::as_stream(stream), nnz, indices,
-                       data, sel, s_entry, static_cast<xc::uint4_t *>(packed));
+                       data, sel, s_entry, hot_slot, static_cast<xc::uint4_t *>(packed));
     XC_CHECK_LAUNCH("pack_rows_kernel");
     return XC_OK;
 }
@@ -988,8 +1060,8 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
                           const int32_t *indices, const void *data, int dtype, int max_row_nnz,
                           int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
                           int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
-                          double *acc, const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
-                          int64_t *changed, const double *ctrl, void *stream) {
+                          const int32_t *hot_labels, double *acc, const xc_metric *metric_host, int maximize, int greedy,
+                          int skip_tn, int n_waves, int64_t *changed, const double *ctrl, void *stream) {
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
         !metric_host)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
@@ -997,6 +1069,8 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: s_entry is required unless greedy");
     if (m > (int64_t)(0xFFFFFFFFu / 16))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: m too large for 32-bit record offsets");
+    if (packed && m > (int64_t)XC_PACK_COL_MASK + 1)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: the packed row stream holds 25-bit column ids");
     if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_sweep_csr: k=%d outside 1..%d", k, XC_MAX_K);
     if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: unknown dtype %d", dtype);
     if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
@@ -1014,14 +1088,15 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
                                  static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
-                                 static_cast<xc::uint4_t *>(packed), acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                 static_cast<xc::uint4_t *>(packed), packed ? hot_labels : nullptr, acc, m,
+                                 (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
                                   static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
-                                  nullptr, acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                  nullptr, nullptr, acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                   (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
@@ -1034,11 +1109,11 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz,
                      int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
                      int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
-                     double *acc, const xc_metric *metric_host, int maximize, int greedy, int skip_tn, int n_waves,
-                     int64_t *changed, void *stream) {
+                     const int32_t *hot_labels, double *acc, const xc_metric *metric_host, int maximize, int greedy,
+                     int skip_tn, int n_waves, int64_t *changed, void *stream) {
     return sweep_csr_impl(n_order, order, n_norm, indptr, indices, data, dtype, max_row_nnz, pred_indices, pred_eta,
-                          sel, orphans, k, m, tpfp, shadow, colsum, s_entry, packed, acc, metric_host, maximize, greedy,
-                          skip_tn, n_waves, changed, nullptr, stream);
+                          sel, orphans, k, m, tpfp, shadow, colsum, s_entry, packed, hot_labels, acc, metric_host,
+                          maximize, greedy, skip_tn, n_waves, changed, nullptr, stream);
 }
 
 // ---- measurement helpers (bench.py): HIP events owned by the library ---------------
@@ -1094,6 +1169,7 @@ struct xc_bca_plan_s {
     double *colsum;
     const double *s_entry;
     void *packed;
+    const int32_t *hot_labels;
     double *acc, *partials;
     xc_metric gain_metric, utility_metric;
     int maximize, skip_tn;
@@ -1102,11 +1178,12 @@ struct xc_bca_plan_s {
 int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total, const int32_t *indptr,
                        const int32_t *indices, const void *data, int dtype, int max_row_nnz, int k,
                        int32_t *pred_indices, void *pred_eta, uint8_t *sel, double *tpfp, float *shadow,
-                       double *colsum, const double *s_entry, void *packed, double *acc, double *partials,
-                       const xc_metric *gain_metric, const xc_metric *utility_metric, int maximize, int skip_tn) {
+                       double *colsum, const double *s_entry, void *packed, const int32_t *hot_labels, double *acc,
+                       double *partials, const xc_metric *gain_metric, const xc_metric *utility_metric, int maximize,
+                       int skip_tn) {
     if (!plan || !gain_metric || !utility_metric) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_create: NULL pointer");
     xc_bca_plan_s *p = new xc_bca_plan_s{n, m, n_total, indptr, indices, data, dtype, max_row_nnz, k, pred_indices,
-                                         pred_eta, sel, tpfp, shadow, colsum, s_entry, packed, acc, partials, *gain_metric,
+                                         pred_eta, sel, tpfp, shadow, colsum, s_entry, packed, hot_labels, acc, partials, *gain_metric,
                                          *utility_metric, maximize, skip_tn};
     *plan = p;
     return XC_OK;
@@ -1123,8 +1200,8 @@ int xc_bca_plan_sweep(void *plan, const int32_t *order, int64_t n_order, const i
     const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
     return xc_bca_sweep_csr(n_order, order, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
                             p->pred_indices, p->pred_eta, p->sel, orphans, p->k, p->m, p->tpfp, p->shadow, p->colsum,
-                            p->s_entry, use_packed ? p->packed : nullptr, with_acc ? p->acc : nullptr, &p->gain_metric, p->maximize, greedy, p->skip_tn,
-                            n_waves, changed, stream);
+                            p->s_entry, use_packed ? p->packed : nullptr, p->hot_labels, with_acc ? p->acc : nullptr,
+                            &p->gain_metric, p->maximize, greedy, p->skip_tn, n_waves, changed, stream);
 }
 
 int xc_bca_plan_boundary(void *plan, int64_t n_norm_utility, double n_counted, int commit, int skip_tn,
@@ -1157,8 +1234,8 @@ int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed
     const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
     return sweep_csr_impl(p->n, order, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
                           p->pred_indices, p->pred_eta, p->sel, nullptr, p->k, p->m, p->tpfp, p->shadow, p->colsum,
-                          p->s_entry, use_packed ? p->packed : nullptr, p->acc, &p->gain_metric, p->maximize, 0,
-                          p->skip_tn, max_waves, nullptr, ctrl, stream);
+                          p->s_entry, use_packed ? p->packed : nullptr, p->hot_labels, p->acc, &p->gain_metric,
+                          p->maximize, 0, p->skip_tn, max_waves, nullptr, ctrl, stream);
 }
 
 int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_counted, int skip_tn, double *ctrl,
