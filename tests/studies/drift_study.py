@@ -3,7 +3,7 @@
 several numbers of concurrent wavefronts against the sequential oracle, with the
 sweep-kernel time and the number of rows whose prediction changed.
 
-    python tools/drift_study.py [n m [zipf]]
+    python tests/studies/drift_study.py [n m [zipf]]
 """
 import json
 import os
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref as oref  # noqa: E402  (checker)
 from xcolumns_amd import _device as D, _lib  # noqa: E402
 from xcolumns_amd.block_coordinate import BcaCsrEngine  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-sweep |utility - sequential oracle| and sweep-kernel time of the DEFAULT concurrency
-policy at several staleness budgets (XCOLUMNS_BCA_STALE_BUDGET).   python tools/policy_study.py [n m [zipf]]"""
+policy at several staleness budgets (XCOLUMNS_BCA_STALE_BUDGET).   python tests/studies/policy_study.py [n m [zipf]]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref as oref  # noqa: E402  (checker)
 from xcolumns_amd import _device as D, _lib  # noqa: E402
 from xcolumns_amd.block_coordinate import BcaCsrEngine, WavePolicy  # noqa: E402

@@ -29,7 +29,7 @@ for step in "$@"; do
         bench_ns) run bench_ns 900 python bench.py --workload ns_1Mx500K --no-cpu-baseline ;;
         bench_c3) run bench_c3 900 python bench.py --workload c3_amazon670k_150Kx670K --no-cpu-baseline ;;
         e2e) run e2e 600 python tools/e2e_api_timing.py ;;
-        drift_ns) run drift_ns 900 python tools/drift_study.py 400000 200000 ;;
+        drift_ns) run drift_ns 900 python tests/studies/drift_study.py 400000 200000 ;;
         *) echo "unknown step $step" ;;
     esac
 done
