@@ -102,6 +102,24 @@ __device__ __forceinline__ unsigned wave_umin32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- all-reduce inside each 16-lane DPP row (quad swaps, then the two row mirrors): every
+// lane ends with its row's result; four VALU instructions, no cross-row traffic ----
+__device__ __forceinline__ unsigned row16_umax32(unsigned v) {
+    v = max(v, dpp_src<0xB1, 0xF>(0u, v));  // quad_perm:[1,0,3,2]
+    v = max(v, dpp_src<0x4E, 0xF>(0u, v));  // quad_perm:[2,3,0,1]
+    v = max(v, dpp_src<0x141, 0xF>(0u, v)); // row_half_mirror
+    v = max(v, dpp_src<0x140, 0xF>(0u, v)); // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ unsigned row16_umin32(unsigned v) {
+    v = min(v, dpp_src<0xB1, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x4E, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x141, 0xF>(~0u, v));
+    v = min(v, dpp_src<0x140, 0xF>(~0u, v));
+    return v;
+}
+
 // 64-bit max / min as two 32-bit reductions: high words first, then the low words
 // of the lanes that hold the winning high word
 __device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {

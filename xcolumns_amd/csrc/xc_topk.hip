@@ -12,6 +12,8 @@
 // a ballot/popcount compaction -- the row is sorted, so lane order is column
 // order.  HBM-bound: 8 B per stored entry in, 4 k (+ 2 x sizeof(T) k) B out.
 #include "xc_common.h"
+#include <stdlib.h>
+
 #include "xc_host.h"
 
 namespace xc {
@@ -168,6 +170,134 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
     }
 }
 
+// ---- float32 rows of at most 64 entries: FOUR rows per wavefront ---------------------
+// The one-row-per-wave kernel above is VALU- and load-issue-bound at these row lengths (k
+// serial wave reductions and dword loads for 50 useful lanes).  Here a 16-lane DPP row owns a
+// matrix row; a lane holds 4 CONSECUTIVE entries (position p = 4 * lane16 + c), fetched as one
+// 16-byte buffer load each from `indices` and `data` (reads past the end of the arrays return 0
+// by the buffer bounds check); the reductions are 4-step butterflies inside the DPP row, and one
+// instruction stream selects for four rows at once.
+typedef unsigned int uint4q_t __attribute__((ext_vector_type(4)));
+#define XC_Q4_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
+#define XC_Q4_CPOL_NT 2             /* streaming loads: do not keep the lines */
+
+__global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float> P) {
+    const int lane = lane_id();
+    const int l16 = lane & 15;
+    const int shift = lane & 48; // bit offset of this DPP row in a wave ballot
+    const int64_t wave = (int64_t)blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    if (wave >= P.n_waves) return;
+    const int64_t G = (int64_t)P.n_waves * 4;
+    const int64_t grp = wave * 4 + (lane >> 4);
+    const int k = P.k;
+    const int64_t last = P.n - 1;
+    const unsigned nnz_bytes = (unsigned)P.indptr[P.n] * 4u;
+    const __amdgpu_buffer_rsrc_t r_idx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(P.indices), 0, nnz_bytes, XC_Q4_RSRC_WORD3);
+    const __amdgpu_buffer_rsrc_t r_eta =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.data), 0, nnz_bytes, XC_Q4_RSRC_WORD3);
+    auto clampr = [&](int64_t r) { return r < last ? r : last; };
+    auto seg16 = [&](unsigned long long mask) { return (unsigned)(mask >> shift) & 0xFFFFu; };
+
+    struct Row { uint4q_t idx, eta; };
+    auto load = [&](int s, Row &d) {
+        const int off = (s + 4 * l16) * 4;
+        d.idx = __builtin_amdgcn_raw_buffer_load_b128(r_idx, off, 0, XC_Q4_CPOL_NT);
+        d.eta = __builtin_amdgcn_raw_buffer_load_b128(r_eta, off, 0, XC_Q4_CPOL_NT);
+    };
+    // software pipeline per DPP row: the entries of its next matrix row and the indptr pair of the
+    // one after are in flight while the current one is selected.  Groups past the end keep
+    // working on (clamped) row n-1 without storing, so the wave stays convergent.
+    int64_t row = grp;
+    int64_t rc = clampr(row);
+    int s0 = P.indptr[rc], e0 = P.indptr[rc + 1];
+    rc = clampr(row + G);
+    int s1 = P.indptr[rc], e1 = P.indptr[rc + 1];
+    Row cur;
+    load(s0, cur);
+    const int64_t iters = (P.n - wave * 4 + G - 1) / G; // of the wave's first DPP row, the longest
+    for (int64_t it = 0; it < iters; ++it, row += G) {
+        const bool live = row < P.n;
+        const int s = s0, r = e0 - s0;
+        Row nxt;
+        load(s1, nxt);
+        rc = clampr(row + 2 * G);
+        const int s2 = P.indptr[rc], e2 = P.indptr[rc + 1];
+        const int64_t w_off = (P.row_cls && live) ? (int64_t)P.row_cls[row] * P.ld : 0;
+
+        int idx[4];
+        float eta[4], gain[4];
+        unsigned key[4];
+        bool sel[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool valid = 4 * l16 + c < r;
+            idx[c] = valid ? (int)cur.idx[c] : 0;
+            eta[c] = __uint_as_float(cur.eta[c]);
+            float g = eta[c];
+            if (P.a) g = g * P.a[w_off + idx[c]]; // numba_csr_functions.py:608-609
+            if (P.b) g = g + P.b[w_off + idx[c]]; // :610-611
+            gain[c] = g;
+            key[c] = valid ? sortable_key32(nan_to_neg_inf(g)) : 0u;
+            sel[c] = false;
+        }
+        const int want = r < k ? r : k; // :465-466: a row of at most k entries keeps them all
+        // the four rows of a wave may need different numbers of rounds: run the maximum
+        const int rounds = (int)wave_umax32((unsigned)want);
+        for (int round = 0; round < rounds; ++round) {
+            // best remaining entry of this lane: highest key, lowest position on ties
+            unsigned lk = 0, lp = 255;
+#pragma unroll
+            for (int c = 3; c >= 0; --c)
+                if (!sel[c] && key[c] != 0u && key[c] >= lk) {
+                    lk = key[c];
+                    lp = (unsigned)(4 * l16 + c);
+                }
+            const unsigned M = row16_umax32(lk);
+            // the winner is the first holder of M in position order (ties go to the lower column)
+            const unsigned Pw = row16_umin32((lk == M && M != 0u) ? lp : 255u);
+            if (round < want && (Pw >> 2) == (unsigned)l16 && Pw != 255u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if ((int)(Pw & 3u) == c) sel[c] = true;
+            }
+        }
+
+        // ascending-column emission inside the DPP row: positions are lane-major
+        int32_t *o_idx = P.out_indices + row * k;
+        float *o_dat = P.out_data ? P.out_data + row * k : nullptr;
+        float *o_eta = P.out_eta ? P.out_eta + row * k : nullptr;
+        const int mine = (int)sel[0] + (int)sel[1] + (int)sel[2] + (int)sel[3];
+        // exclusive prefix of `mine` over the lower lanes of the DPP row, from the per-entry ballots
+        int before = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) before += __popc(seg16(__ballot(sel[c])) & ((1u << l16) - 1u));
+        int slot = before;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (sel[c] && live) {
+                o_idx[slot] = idx[c];
+                if (o_dat) o_dat[slot] = P.keep_scores ? gain[c] : 1.0f;
+                if (o_eta) o_eta[slot] = eta[c];
+            }
+            slot += sel[c] ? 1 : 0;
+            if (P.out_sel && live && 4 * l16 + c < r) P.out_sel[s + 4 * l16 + c] = sel[c] ? 1 : 0;
+        }
+        (void)mine;
+        // :599-601: slots a short row leaves unused keep column 0 / value 1
+        if (live)
+            for (int q = want + l16; q < k; q += 16) {
+                o_idx[q] = 0;
+                if (o_dat) o_dat[q] = 1.0f;
+                if (o_eta) o_eta[q] = 0.0f;
+            }
+
+        cur = nxt;
+        s0 = s1; e0 = e1;
+        s1 = s2; e1 = e2;
+    }
+}
+
 // ---- k == 0: keep entries with gain >= th (numba_csr_functions.py:516-517) ----
 template <typename T, bool FILL>
 __global__ __launch_bounds__(XC_BLOCK) void threshold_csr_kernel(
@@ -234,6 +364,36 @@ static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices,
     return 0;
 }
 
+// XCOLUMNS_TOPK_ONE_ROW_PER_WAVE=1 keeps the one-row-per-wave kernel for short float32 rows too
+// (A/B measurements)
+static const bool g_topk_one_row_per_wave = [] {
+    const char *e = getenv("XCOLUMNS_TOPK_ONE_ROW_PER_WAVE");
+    return e && e[0] == '1';
+}();
+
+static int launch_topk_q4(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data, int k,
+                          const void *a, const void *b, int64_t ld, const int32_t *row_cls, int keep_scores,
+                          int32_t *out_indices, void *out_data, void *out_eta, uint8_t *out_sel, hipStream_t st) {
+    TopkParams<float> P;
+    P.n = n;
+    P.indptr = indptr;
+    P.indices = indices;
+    P.data = static_cast<const float *>(data);
+    P.a = static_cast<const float *>(a);
+    P.b = static_cast<const float *>(b);
+    P.row_cls = row_cls;
+    P.ld = ld;
+    P.k = k;
+    P.keep_scores = keep_scores;
+    P.out_indices = out_indices;
+    P.out_data = static_cast<float *>(out_data);
+    P.out_eta = static_cast<float *>(out_eta);
+    P.out_sel = out_sel;
+    P.n_waves = default_row_waves((n + 3) / 4);
+    hipLaunchKernelGGL(topk_csr_q4_kernel, dim3((P.n_waves + 3) / 4), dim3(XC_BLOCK), 0, st, P);
+    return 0;
+}
+
 } // namespace xc
 
 extern "C" {
@@ -250,7 +410,9 @@ int xc_topk_csr(int64_t n, const int32_t *indptr, const int32_t *indices, const 
         return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_topk_csr: a row holds %d entries, limit %d", max_row_nnz, XC_MAX_ROW_NNZ);
     if (n == 0) return XC_OK;
     hipStream_t st = xc::as_stream(stream);
-    if (dtype == XC_F32)
+    if (dtype == XC_F32 && max_row_nnz <= 64 && n < (1 << 24) && !xc::g_topk_one_row_per_wave)
+        xc::launch_topk_q4(n, indptr, indices, data, k, a, b, 0, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, st);
+    else if (dtype == XC_F32)
         xc::launch_topk<float>(n, indptr, indices, data, k, a, b, 0, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
     else
         xc::launch_topk<double>(n, indptr, indices, data, k, a, b, 0, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
@@ -317,7 +479,9 @@ int xc_topk_csr_rowwise(int64_t n, const int32_t *indptr, const int32_t *indices
     if (n == 0) return XC_OK;
     hipStream_t st = xc::as_stream(stream);
     // only the chosen column ids are produced: the prediction's values are all ones
-    if (dtype == XC_F32)
+    if (dtype == XC_F32 && max_row_nnz <= 64 && n < (1 << 24) && !xc::g_topk_one_row_per_wave)
+        xc::launch_topk_q4(n, indptr, indices, data, k, a, b, ld, row_classifier, 0, out_indices, nullptr, nullptr, nullptr, st);
+    else if (dtype == XC_F32)
         xc::launch_topk<float>(n, indptr, indices, data, k, a, b, ld, row_classifier, 0, out_indices, nullptr, nullptr, nullptr, ch, st);
     else
         xc::launch_topk<double>(n, indptr, indices, data, k, a, b, ld, row_classifier, 0, out_indices, nullptr, nullptr, nullptr, ch, st);
