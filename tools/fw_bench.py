@@ -49,7 +49,7 @@ b = np.full(m, -0.5, dtype=np.float32)
 stats = timed("predict+confusion", lambda: eng.confusion_of(a, b), acc)
 for it in range(iters):
     a, b = timed("gradient", lambda: eng.next_classifier(stats), acc)
-    stats_i = timed("predict+confusion", lambda: eng.confusion_of(a.astype(np.float32), b.astype(np.float32)), acc)
+    stats_i = timed("predict+confusion", lambda: eng.confusion_of(a, b), acc)
     timed("utility", lambda: eng.utility(stats_i), acc)
     alpha = timed("alpha search (10^4 points)", lambda: eng.best_alpha(stats, stats_i, "uniform", 1e-3, 1e-4), acc)
     stats = (1 - alpha) * stats + alpha * stats_i

@@ -182,6 +182,7 @@ class FwEngine:
         """float64 (4, m) on the GPU: tp | fp | fn | tn of predict_weighted_per_instance(y_proba, k,
         th=0.0, a, b) against y_true, normalised / rounded as the reference's calculate_confusion_matrix."""
         if self.sparse:
+            # `a`, `b`: the float32 table rows, on the host or already on the GPU (next_classifier)
             a_d = D.to_device(a, dtype=self.weight_dtype, device=self.dev)
             b_d = D.to_device(b, dtype=self.weight_dtype, device=self.dev)
             if self.k > 0:
@@ -223,16 +224,18 @@ class FwEngine:
         total = _finish_sum(self.partials)
         return total / self.m if self.obj.average == "macro" else total
 
-    def next_classifier(self, stats: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
-        """frank_wolfe.py:585-596: (a, b) float64 vectors from the gradient at `stats`."""
+    def next_classifier(self, stats: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """frank_wolfe.py:585-596: (a, b) from the gradient at `stats`, rounded to the classifier
+        tables' float32 (types.py:13) and left on the GPU: the next prediction reads them there, the
+        host keeps a copy for the returned classifier."""
         s, m = self._reduced(stats)
         ab = torch.empty((2, m), dtype=torch.float64, device=self.dev)
         div = float(self.m) if self.obj.average == "macro" else 1.0
         _lib.call("xc_fw_gradient", m, D.ptr(s), ctypes.byref(self.metric), div, int(not self.maximize),
                   D.ptr(ab[0]), D.ptr(ab[1]), D.stream())
-        ab = ab.cpu().numpy()
+        ab = ab.to(torch.float32)
         if m == 1:
-            return np.full(self.m, ab[0, 0]), np.full(self.m, ab[1, 0])
+            ab = ab.expand(2, self.m).contiguous()
         return ab[0], ab[1]
 
     def curve(self, cur: torch.Tensor, nxt: torch.Tensor, alphas: np.ndarray) -> np.ndarray:
@@ -521,8 +524,11 @@ def find_classifier_using_fw(
     for i in range(1, max_iters + 1):
         log_info(f"  Starting iteration {i}/{max_iters} ...", verbose)
         old_utility = new_utility  # the utility at `stats` (:585-587)
-        A[i], B[i] = eng.next_classifier(stats)
-        stats_i = eng.confusion_of(A[i], B[i])
+        a_i, b_i = eng.next_classifier(stats)
+        A[i] = a_i.cpu().numpy() if isinstance(a_i, torch.Tensor) else a_i
+        B[i] = b_i.cpu().numpy() if isinstance(b_i, torch.Tensor) else b_i
+        stats_i = eng.confusion_of(a_i if isinstance(a_i, torch.Tensor) else A[i],
+                                   b_i if isinstance(b_i, torch.Tensor) else B[i])
         utility_i = eng.utility(stats_i)
         log_info(f"    Metric value of new (sub)classifier {i}: {utility_i}", verbose)
         if search_for_best_alpha:
