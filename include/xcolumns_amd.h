@@ -319,6 +319,16 @@ int xc_bca_sweep_dense(int64_t n_order, const int32_t *order, int64_t n_norm,
                        double *stats, double *workspace, const xc_metric *metric_host,
                        int maximize, int greedy, int skip_tn, void *stream);
 
+/* The same step with `n_blocks` workgroups walking `order` concurrently (block b takes
+ * positions b, b + n_blocks, ...; non-greedy sweeps, m <= 8192): statistics are read
+ * coherently and only the labels whose prediction flips are pushed back, as float64
+ * atomics.  Rows in flight miss each other's update, exactly as in xc_bca_sweep_csr
+ * with n_waves > 1.  changed: optional int64[1], += rows whose prediction changed. */
+int xc_bca_sweep_dense_concurrent(int64_t n_order, const int32_t *order, int64_t n_norm,
+                                  int64_t m, const void *y_proba, void *y_pred, int dtype, int k,
+                                  double *stats, const xc_metric *metric_host, int maximize,
+                                  int skip_tn, int n_blocks, int64_t *changed, void *stream);
+
 /* Utility of four plain vectors (dense path): partials as above. */
 int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
                        const xc_metric *metric_host, double *partials, void *stream);

@@ -187,7 +187,7 @@ def test_bca_dense_golden(tag, kind):
     Yin = Y if kind == "numpy" else torch.from_numpy(Y).cuda()
     for name in [str(s) for s in z["names"]]:
         spec = G.spec_of(z, name)
-        P, meta = G.product_call_from_spec(spec, Yin)
+        P, meta = G.product_call_from_spec(spec, Yin, bca_waves=1)
         _check_bca(P, meta, z, name, "pred_" + name, 1e-12)
         assert type(P) == type(Yin) and P.dtype == Yin.dtype
         got = P if kind == "numpy" else P.cpu().numpy()
@@ -612,3 +612,42 @@ def test_pipelined_and_host_paced_loops_agree(monkeypatch, oref):
     assert np.abs(np.asarray(a) - np.asarray(b)).max() < PER_SWEEP_TOL
     assert abs(a[-1] - b[-1]) < FINAL_TOL
     assert runs["1"]["wavefronts"] == runs["0"]["wavefronts"] == [64] * 6
+
+
+# ---------------------------------------------------------------------------
+# dense BCA, concurrent mode (the product default) against the oracle
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype,k,skip_tn,entry", [
+    (np.float32, 5, True, "predict_optimizing_macro_f1_score_using_bc"),
+    (np.float64, 3, False, "predict_optimizing_macro_balanced_accuracy_using_bc"),
+    (np.float32, 0, True, "predict_optimizing_macro_f1_score_using_bc"),
+])
+def test_bca_dense_concurrent_vs_oracle(oref, dtype, k, skip_tn, entry):
+    """Dense y_proba with the default policy (several workgroups walk the order): final utility within
+    1e-5 of the sequential oracle after the same number of sweeps, every sweep within PER_SWEEP_TOL;
+    bca_waves=1 reproduces it to 1e-12."""
+    import xcolumns_amd.block_coordinate as bc
+    rng = np.random.default_rng(21)
+    n, m = 6000, 1500
+    Y = (rng.random((n, m)) ** 6).astype(dtype)
+    base = {"predict_optimizing_macro_f1_score_using_bc": oref.FBETA,
+            "predict_optimizing_macro_balanced_accuracy_using_bc": oref.BALANCED_ACC}[entry]
+    metric = oref.make_metric(base, k=float(max(k, 1)), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=skip_tn, seed=13, max_iters=4, tolerance=-1.0)
+    Pg, mg = getattr(bc, entry)(Y, k, seed=13, max_iters=4, tolerance=-1.0, return_meta=True, bca_diagnostics=True)
+    assert mg["iters"] == 4 and type(Pg) == type(Y) and Pg.dtype == Y.dtype and Pg.shape == Y.shape
+    diff = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print("dense concurrent-vs-sequential utility diff per sweep:", diff)
+    if k == 0:   # no budget: the product keeps the sequential sweep
+        assert diff.max() < 1e-12
+    assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL, (mg["utilities"], mo["utilities"])
+    if k > 0:
+        assert (Pg.sum(axis=1) == k).all()
+    assert np.isin(Pg, (0, 1)).all()
+    # the reported utility is the utility of the returned prediction
+    tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, Pg, skip_tn=skip_tn)
+    u = oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n)
+    assert abs(u - mg["utilities"][-1]) < 1e-12
+    Pe, me = getattr(bc, entry)(Y, k, seed=13, max_iters=4, tolerance=-1.0, return_meta=True, bca_waves=1)
+    assert np.allclose(me["utilities"], mo["utilities"], rtol=0, atol=1e-12) and np.array_equal(Pe, Po)

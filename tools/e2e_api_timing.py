@@ -52,5 +52,11 @@ t0 = time.perf_counter()
 Pb, mb = _bc(Yg, 5, seed=0, max_iters=3, tolerance=-1e9, return_meta=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+t1 = time.perf_counter()
+Pb1, mb1 = _bc(Yg, 5, seed=0, max_iters=3, tolerance=-1e9, return_meta=True, bca_waves=1)
+torch.cuda.synchronize()
+dt1 = time.perf_counter() - t1
+print(f"C1 dense BCA macro-F1, 3 sweeps, bca_waves=1 (sequential, exact): {dt1 * 1e3:.1f} ms -> {3865 * 3 / dt1 / 1e3:.1f} K rows/s, "
+      f"utilities {mb1['utilities']}")
 print(f"C1 dense BCA macro-F1, 3 sweeps (torch GPU tensor): {dt * 1e3:.1f} ms -> {3865 * 3 / dt / 1e3:.1f} K rows/s, "
       f"utilities {mb['utilities']}")

@@ -110,6 +110,8 @@ SIGNATURES = {
     "xc_bca_sweep_dense": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                    c_int, c_void_p, c_void_p, POINTER(XcMetric), c_int, c_int, c_int,
                                    c_void_p]),
+    "xc_bca_sweep_dense_concurrent": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
+                                              c_void_p, POINTER(XcMetric), c_int, c_int, c_int, c_void_p, c_void_p]),
     "xc_utility_vectors": (c_int, [c_int64, c_int64, c_void_p, POINTER(XcMetric), c_void_p, c_void_p]),
 }
 

@@ -606,8 +606,12 @@ def _dense_utility(stats: torch.Tensor, n_u: int, metric_c, partials: torch.Tens
     return out.value
 
 
+_DENSE_BLOCK_WAVES = 16       # a dense row is scored by one 1024-thread workgroup
+_DENSE_MAX_LABELS = 8192      # xc_bca_sweep_dense_concurrent keeps <= 8 labels per thread in registers
+
+
 def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance, init_y_pred,
-              max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend):
+              max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend, bca_waves=None):
     n_rows, m = y_proba.shape
     if k < 0:
         raise ValueError("k must be >= 0")
@@ -642,6 +646,12 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
     work = torch.empty(m, dtype=torch.float64, device=dev)
     partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=dev)
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
+    # rows in flight: the CSR policy (one workgroup here = one "wavefront" there), bounded by the
+    # workgroups the GPU holds; bca_waves=1 is the reference's sequential sweep
+    policy = WavePolicy(n_u, fixed=bca_waves)
+    max_blocks = max(1, policy.cap // _DENSE_BLOCK_WAVES)
+    changed = torch.zeros(1, dtype=torch.int64, device=dev)
+    changed_prev = None
     for j in range(1, max_iters + 1):
         log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
         order = orders.next()
@@ -654,9 +664,20 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
         if metric_aggregation == "mean":
             old_utility /= m
         log_info("    Doing block coordinate optimization steps ...", verbose)
-        _lib.call("xc_bca_sweep_dense", int(n_u), D.ptr(order), int(n_rows), int(m), D.ptr(y), D.ptr(y_pred),
-                  D.dtype_code(y.dtype), int(k), D.ptr(stats), D.ptr(work), ctypes.byref(gain_c), int(maximize),
-                  int(greedy), int(skip_tn), D.stream())
+        n_blocks = min(policy.next(changed_prev), max_blocks)
+        # k == 0 (no budget) flips many labels per row: rows in flight would miss too much of each
+        # other (2.6e-4 in the first sweep at 6000 x 1500), so it stays sequential
+        if greedy or n_blocks == 1 or m > _DENSE_MAX_LABELS or k == 0:
+            _lib.call("xc_bca_sweep_dense", int(n_u), D.ptr(order), int(n_rows), int(m), D.ptr(y), D.ptr(y_pred),
+                      D.dtype_code(y.dtype), int(k), D.ptr(stats), D.ptr(work), ctypes.byref(gain_c), int(maximize),
+                      int(greedy), int(skip_tn), D.stream())
+            changed_prev = None
+        else:
+            changed.zero_()
+            _lib.call("xc_bca_sweep_dense_concurrent", int(n_u), D.ptr(order), int(n_rows), int(m), D.ptr(y),
+                      D.ptr(y_pred), D.dtype_code(y.dtype), int(k), D.ptr(stats), ctypes.byref(gain_c), int(maximize),
+                      int(skip_tn), int(n_blocks), D.ptr(changed), D.stream())
+            changed_prev = int(changed.item())
         _dense_confusion(y, y_pred, stats, skip_tn)   # :465-467
         new_utility = _dense_utility(stats, n_u, util_c, partials)
         if metric_aggregation == "mean":
@@ -751,7 +772,8 @@ def predict_using_bc_with_0approx(
                          order_backend)
     else:
         y_pred = _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
-                           init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend)
+                           init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend,
+                           bca_waves)
 
     if not bca_diagnostics:
         meta.pop("wavefronts", None)

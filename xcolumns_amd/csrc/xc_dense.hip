@@ -376,6 +376,106 @@ __global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_reg_kernel(Den
     }
 }
 
+// ---- concurrent dense sweep ------------------------------------------------------
+// The dense step touches every label of a row, but only the labels whose prediction flips
+// change the statistics.  So, as in the CSR sweep, `n_blocks` workgroups walk the order
+// interleaved (block b takes positions b, b + n_blocks, ...): each reads the four statistic
+// vectors coherently (sc1, L2-served), removes its row's own contribution in registers,
+// scores all m labels, selects with the same block-wide rounds as above, and pushes float64
+// atomics for the flipped labels only.  Rows in flight miss each other's update (DESIGN.md
+// "staleness"); n_blocks = 1 is NOT this kernel but the sequential one above.
+template <typename T, int EPT>
+__global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_conc_kernel(DenseSweepParams<T> P, xc_metric fast,
+                                                                           unsigned long long *changed) {
+    __shared__ unsigned long long red64[XC_DENSE_BLOCK / XC_WAVE];
+    __shared__ unsigned red32[XC_DENSE_BLOCK / XC_WAVE];
+    const int64_t m = P.m;
+    const T one = (T)1;
+    unsigned long long n_changed = 0;
+    for (int64_t pos = blockIdx.x; pos < P.n_order; pos += gridDim.x) {
+        const int64_t row = P.order ? (int64_t)P.order[pos] : pos;
+        const T *prob = P.y_proba + row * m;
+        T *pred = P.y_pred + row * m;
+        T t_cur[EPT], p_cur[EPT];
+        unsigned long long keys[EPT];
+        bool nonneg[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+            const bool v = j < m;
+            const T t = v ? prob[j] : (T)0, p = v ? pred[j] : (T)0;
+            t_cur[e] = t;
+            p_cur[e] = p;
+            const T om = one - t;
+            // block_coordinate.py:157-163 in registers, on statistics other rows keep updating
+            double tp = v ? load_coherent(P.tp + j) : 0.0, fp = v ? load_coherent(P.fp + j) : 0.0;
+            double fn = v ? load_coherent(P.fn + j) : 0.0, tn = v ? load_coherent(P.tn + j) : 0.0;
+            tp -= (double)(T)(p * t);
+            fp -= (double)(T)(p * om);
+            fn -= (double)(T)((one - p) * t);
+            if (!P.skip_tn) tn -= (double)(T)((one - p) * om);
+            // :166-185; psi(x / n; eps, k) = psi(x; eps * n, k * n): `fast` carries the rescaled constants
+            double neg_tn = tn;
+            if (!P.skip_tn) neg_tn = tn + (double)om;
+            double g = metric_eval_t<false>(fast, tp + (double)t, fp + (double)om, fn, tn) -
+                       metric_eval_t<false>(fast, tp, fp, fn + (double)t, neg_tn);
+            if (!P.maximize) g = -g;
+            keys[e] = v ? sortable_key(nan_to_neg_inf(g)) : 0ull;
+            nonneg[e] = (-g) <= 0.0; // :199-200 on the negated gains (k == 0)
+        }
+
+        unsigned long long mine = 0ull;
+        if (P.k > 0) {
+            unsigned long long prev_key = ~0ull;
+            unsigned prev_col = 0u;
+            bool first = true;
+            const int rounds = (int64_t)P.k < m ? P.k : (int)m;
+            for (int round = 0; round < rounds; ++round) {
+                unsigned long long best = 0ull;
+                unsigned col = ~0u;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const unsigned j = threadIdx.x + e * XC_DENSE_BLOCK;
+                    const bool rem = first || keys[e] < prev_key || (keys[e] == prev_key && j > prev_col);
+                    if (rem && keys[e] > best) best = keys[e];
+                }
+                best = block_umax64<XC_DENSE_BLOCK>(best, red64);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const unsigned j = threadIdx.x + e * XC_DENSE_BLOCK;
+                    const bool rem = first || keys[e] < prev_key || (keys[e] == prev_key && j > prev_col);
+                    if (rem && keys[e] == best && j < col) col = j;
+                }
+                col = block_umin32<XC_DENSE_BLOCK>(col, red32);
+                if ((col % XC_DENSE_BLOCK) == threadIdx.x) mine |= 1ull << (col / XC_DENSE_BLOCK);
+                prev_key = best;
+                prev_col = col;
+                first = false;
+            }
+        }
+
+        bool flipped = false;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t j = threadIdx.x + (int64_t)e * XC_DENSE_BLOCK;
+            const bool sel = P.k > 0 ? (((mine >> e) & 1ull) != 0ull) : nonneg[e];
+            const T p = sel ? one : (T)0;
+            if (j < m && p != p_cur[e]) { // :191-209 net of :157-163: only a flipped label moves
+                const T t = t_cur[e], om = one - t;
+                const double d = (double)p - (double)p_cur[e]; // +1 or -1 for 0/1 predictions
+                pred[j] = p;
+                atomic_add_f64(P.tp + j, d * (double)t);
+                atomic_add_f64(P.fp + j, d * (double)om);
+                atomic_add_f64(P.fn + j, -d * (double)t);
+                if (!P.skip_tn) atomic_add_f64(P.tn + j, -d * (double)om);
+                flipped = true;
+            }
+        }
+        if (__syncthreads_or(flipped ? 1 : 0)) ++n_changed;
+    }
+    if (threadIdx.x == 0 && n_changed && changed) atomicAdd(changed, n_changed);
+}
+
 } // namespace xc
 
 extern "C" {
@@ -434,6 +534,46 @@ int xc_bca_sweep_dense(int64_t n_order, const int32_t *order, int64_t n_norm, in
         else hipLaunchKernelGGL((xc::bca_sweep_dense_kernel<double, 0>), dim3(1), dim3(XC_DENSE_BLOCK), 0, st, P);
     }
     XC_CHECK_LAUNCH("bca_sweep_dense_kernel");
+    return XC_OK;
+}
+
+int xc_bca_sweep_dense_concurrent(int64_t n_order, const int32_t *order, int64_t n_norm, int64_t m,
+                                  const void *y_proba, void *y_pred, int dtype, int k, double *stats,
+                                  const xc_metric *metric_host, int maximize, int skip_tn, int n_blocks,
+                                  int64_t *changed, void *stream) {
+    if (n_order < 0 || n_norm < 1 || m < 1 || !y_proba || !y_pred || !stats || !metric_host || n_blocks < 1)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_dense_concurrent: NULL pointer or bad size");
+    if (k < 0) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_sweep_dense_concurrent: k=%d is negative", k);
+    if (dtype != XC_F32 && dtype != XC_F64)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_dense_concurrent: unknown dtype %d", dtype);
+    if (metric_host->base < 0 || metric_host->base >= XC_M_COUNT)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_dense_concurrent: unknown metric %d", metric_host->base);
+    if (m > (int64_t)XC_DENSE_BLOCK * 8)
+        return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_bca_sweep_dense_concurrent: m=%lld exceeds %d", (long long)m,
+                            XC_DENSE_BLOCK * 8);
+    if (n_order == 0) return XC_OK;
+    if (n_blocks > n_order) n_blocks = (int)n_order;
+    hipStream_t st = xc::as_stream(stream);
+    xc_metric fast = *metric_host; // psi(x / n; eps, k) = psi(x; eps * n, k * n)
+    fast.epsilon *= (double)n_norm;
+    fast.kf *= (double)n_norm;
+    unsigned long long *ch = reinterpret_cast<unsigned long long *>(changed);
+    if (dtype == XC_F32) {
+        xc::DenseSweepParams<float> P{n_order, order, m, static_cast<const float *>(y_proba), static_cast<float *>(y_pred), k,
+                                      stats, stats + m, stats + 2 * m, stats + 3 * m, nullptr, *metric_host,
+                                      (double)n_norm, maximize, 0, skip_tn};
+        if (m <= 1 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_conc_kernel<float, 1>), dim3(n_blocks), dim3(XC_DENSE_BLOCK), 0, st, P, fast, ch);
+        else if (m <= 4 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_conc_kernel<float, 4>), dim3(n_blocks), dim3(XC_DENSE_BLOCK), 0, st, P, fast, ch);
+        else hipLaunchKernelGGL((xc::bca_sweep_dense_conc_kernel<float, 8>), dim3(n_blocks), dim3(XC_DENSE_BLOCK), 0, st, P, fast, ch);
+    } else {
+        xc::DenseSweepParams<double> P{n_order, order, m, static_cast<const double *>(y_proba), static_cast<double *>(y_pred), k,
+                                       stats, stats + m, stats + 2 * m, stats + 3 * m, nullptr, *metric_host,
+                                       (double)n_norm, maximize, 0, skip_tn};
+        if (m <= 1 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_conc_kernel<double, 1>), dim3(n_blocks), dim3(XC_DENSE_BLOCK), 0, st, P, fast, ch);
+        else if (m <= 4 * XC_DENSE_BLOCK) hipLaunchKernelGGL((xc::bca_sweep_dense_conc_kernel<double, 4>), dim3(n_blocks), dim3(XC_DENSE_BLOCK), 0, st, P, fast, ch);
+        else hipLaunchKernelGGL((xc::bca_sweep_dense_conc_kernel<double, 8>), dim3(n_blocks), dim3(XC_DENSE_BLOCK), 0, st, P, fast, ch);
+    }
+    XC_CHECK_LAUNCH("bca_sweep_dense_conc_kernel");
     return XC_OK;
 }
 
