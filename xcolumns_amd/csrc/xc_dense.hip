@@ -105,6 +105,45 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_dense_kernel(int64_t m, int64_t
     }
 }
 
+// float32 gains of at most 32 * XC_BLOCK labels: the row is read ONCE into registers as 64-bit keys (sortable gain << 32 | ~column) and the k rounds run
+// on registers; the output row is written once (zeros and the winners together).
+template <typename P, int EPT>
+__global__ __launch_bounds__(XC_BLOCK) void topk_dense_reg_kernel(int64_t m, int64_t ld, const float *gains, int k,
+                                                                  int keep_scores, P *y_pred) {
+    __shared__ unsigned long long red64[XC_BLOCK / XC_WAVE];
+    const int64_t row = blockIdx.x;
+    const float *g = gains + row * ld;
+    P *o = y_pred + row * m;
+    float val[EPT];
+    unsigned long long key[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t j = threadIdx.x + (int64_t)e * XC_BLOCK;
+        val[e] = j < m ? __builtin_nontemporal_load(g + j) : 0.0f;
+        key[e] = j < m ? (((unsigned long long)sortable_key32(nan_to_neg_inf(val[e])) << 32) | (unsigned)(~(unsigned)j))
+                       : 0ull;
+    }
+    unsigned picked = 0u; // bit e: this thread's e-th label is among the k winners
+    const int rounds = (int64_t)k < m ? k : (int)m;
+    unsigned long long prev = ~0ull;
+    for (int round = 0; round < rounds; ++round) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (key[e] < prev && key[e] > best) best = key[e];
+        best = block_umax64<XC_BLOCK>(best, red64);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (key[e] == best && best != 0ull) picked |= 1u << e;
+        prev = best;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t j = threadIdx.x + (int64_t)e * XC_BLOCK;
+        if (j < m) o[j] = ((picked >> e) & 1u) ? (keep_scores ? (P)val[e] : (P)1) : (P)0; // weighted_prediction.py:35, :47-49
+    }
+}
+
 // ---- dense BCA sweep -----------------------------------------------------------
 #define XC_DENSE_BLOCK 1024
 #define XC_DENSE_MAX_EPT 64 /* labels per thread tracked in the selection mask */
@@ -491,7 +530,24 @@ int xc_topk_dense(int64_t n, int64_t m, int64_t ld, const void *gains, int gdtyp
     if (n == 0 || m == 0) return XC_OK;
     hipStream_t st = xc::as_stream(stream);
     dim3 grid((unsigned)n), block(XC_BLOCK);
-    if (gdtype == XC_F32 && pdtype == XC_F32)
+    if (gdtype == XC_F32 && k > 0 && m <= 32 * XC_BLOCK) { // the row fits in registers: one read, one write
+        const float *gf = static_cast<const float *>(gains);
+#define XC_TOPK_REG(PT, EPT)                                                                                     \
+    hipLaunchKernelGGL((xc::topk_dense_reg_kernel<PT, EPT>), grid, block, 0, st, m, ld, gf, k, keep_scores,      \
+                       static_cast<PT *>(y_pred))
+#define XC_TOPK_REG_BY_M(PT)                       \
+    do {                                           \
+        if (m <= 2 * XC_BLOCK) XC_TOPK_REG(PT, 2); \
+        else if (m <= 4 * XC_BLOCK) XC_TOPK_REG(PT, 4); \
+        else if (m <= 8 * XC_BLOCK) XC_TOPK_REG(PT, 8); \
+        else if (m <= 16 * XC_BLOCK) XC_TOPK_REG(PT, 16); \
+        else XC_TOPK_REG(PT, 32);                  \
+    } while (0)
+        if (pdtype == XC_F32) XC_TOPK_REG_BY_M(float);
+        else XC_TOPK_REG_BY_M(double);
+#undef XC_TOPK_REG_BY_M
+#undef XC_TOPK_REG
+    } else if (gdtype == XC_F32 && pdtype == XC_F32)
         hipLaunchKernelGGL((xc::topk_dense_kernel<float, float>), grid, block, 0, st, m, ld, static_cast<const float *>(gains), k, (float)th, keep_scores, static_cast<float *>(y_pred));
     else if (gdtype == XC_F64 && pdtype == XC_F32)
         hipLaunchKernelGGL((xc::topk_dense_kernel<double, float>), grid, block, 0, st, m, ld, static_cast<const double *>(gains), k, th, keep_scores, static_cast<float *>(y_pred));

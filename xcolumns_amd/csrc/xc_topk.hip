@@ -267,8 +267,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         int32_t *o_idx = P.out_indices + row * k;
         float *o_dat = P.out_data ? P.out_data + row * k : nullptr;
         float *o_eta = P.out_eta ? P.out_eta + row * k : nullptr;
-        const int mine = (int)sel[0] + (int)sel[1] + (int)sel[2] + (int)sel[3];
-        // exclusive prefix of `mine` over the lower lanes of the DPP row, from the per-entry ballots
+        // selected entries held by the lower lanes of the DPP row, from the per-entry ballots
         int before = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) before += __popc(seg16(__ballot(sel[c])) & ((1u << l16) - 1u));
@@ -283,7 +282,6 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
             slot += sel[c] ? 1 : 0;
             if (P.out_sel && live && 4 * l16 + c < r) P.out_sel[s + 4 * l16 + c] = sel[c] ? 1 : 0;
         }
-        (void)mine;
         // :599-601: slots a short row leaves unused keep column 0 / value 1
         if (live)
             for (int q = want + l16; q < k; q += 16) {

@@ -175,7 +175,6 @@ class FwEngine:
             self.proba = yp.to(self.dev).contiguous()
             self.stat_dtype = self.true.dtype
         self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=self.dev)
-        self._alpha_cache: Dict[Tuple[float, float], Tuple[np.ndarray, torch.Tensor, torch.Tensor]] = {}
 
     # -- one weighted classifier -> its confusion matrix (frank_wolfe.py:560-566, :599-604) --
     def confusion_of(self, a: np.ndarray, b: np.ndarray) -> torch.Tensor:
