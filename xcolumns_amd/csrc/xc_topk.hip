@@ -26,6 +26,7 @@ struct TopkParams {
     const T *data;
     const T *a;
     const T *b;
+    const T *ab;            // optional instead of a, b: interleaved {a[col], b[col]}, ONE gather per candidate
     const int32_t *row_cls; // optional: row i uses a + row_cls[i] * ld, b + row_cls[i] * ld
     int64_t ld;
     int k;
@@ -108,8 +109,14 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_kernel(TopkParams<T> P) {
         for (int c = 0; c < CH; ++c) {
             const bool valid = lane + XC_WAVE * c < r;
             T g = cur.eta[c];
-            if (P.a) g = g * P.a[w_off + cur.idx[c]]; // numba_csr_functions.py:608-609
-            if (P.b) g = g + P.b[w_off + cur.idx[c]]; // :610-611
+            if (P.ab) {
+                typedef T pair_t __attribute__((ext_vector_type(2)));
+                const pair_t w = *reinterpret_cast<const pair_t *>(P.ab + 2 * (int64_t)cur.idx[c]);
+                g = g * w.x; // numba_csr_functions.py:608-609
+                g = g + w.y; // :610-611
+            }
+            if (P.a) g = g * P.a[w_off + cur.idx[c]];
+            if (P.b) g = g + P.b[w_off + cur.idx[c]];
             gain[c] = g;
             key[c] = valid ? KeyOf<T>::make(g) : (key_t)0;
             sel[c] = false;
@@ -235,8 +242,14 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
             idx[c] = valid ? (int)cur.idx[c] : 0;
             eta[c] = __uint_as_float(cur.eta[c]);
             float g = eta[c];
-            if (P.a) g = g * P.a[w_off + idx[c]]; // numba_csr_functions.py:608-609
-            if (P.b) g = g + P.b[w_off + idx[c]]; // :610-611
+            if (P.ab) {
+                typedef float pair_t __attribute__((ext_vector_type(2)));
+                const pair_t w = *reinterpret_cast<const pair_t *>(P.ab + 2 * (int64_t)idx[c]);
+                g = g * w.x; // numba_csr_functions.py:608-609
+                g = g + w.y; // :610-611
+            }
+            if (P.a) g = g * P.a[w_off + idx[c]];
+            if (P.b) g = g + P.b[w_off + idx[c]];
             gain[c] = g;
             key[c] = valid ? sortable_key32(nan_to_neg_inf(g)) : 0u;
             sel[c] = false;
@@ -342,6 +355,12 @@ static int launch_topk(int64_t n, const int32_t *indptr, const int32_t *indices,
     P.data = static_cast<const T *>(data);
     P.a = static_cast<const T *>(a);
     P.b = static_cast<const T *>(b);
+    P.ab = nullptr;
+    if (ld < 0) { // `a` carries the interleaved table
+        P.ab = P.a;
+        P.a = P.b = nullptr;
+        ld = 0;
+    }
     P.row_cls = row_cls;
     P.ld = ld;
     P.k = k;
@@ -379,6 +398,12 @@ static int launch_topk_q4(int64_t n, const int32_t *indptr, const int32_t *indic
     P.data = static_cast<const float *>(data);
     P.a = static_cast<const float *>(a);
     P.b = static_cast<const float *>(b);
+    P.ab = nullptr;
+    if (ld < 0) { // `a` carries the interleaved table
+        P.ab = P.a;
+        P.a = P.b = nullptr;
+        ld = 0;
+    }
     P.row_cls = row_cls;
     P.ld = ld;
     P.k = k;
@@ -461,6 +486,29 @@ int xc_threshold_fill_csr(int64_t n, const int32_t *indptr, const int32_t *indic
                           int32_t *out_indices, void *stream) {
     if (n > 0 && !out_indptr) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_threshold_fill_csr: out_indptr is NULL");
     return threshold_common(true, n, indptr, indices, data, dtype, th, a, b, 0, nullptr, nullptr, out_indptr, out_indices, stream);
+}
+
+// ---- weights given interleaved: ab[2 col] = a[col], ab[2 col + 1] = b[col] ----
+int xc_topk_csr_ab(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data, int dtype,
+                   int max_row_nnz, int k, const void *ab, int keep_scores, int32_t *out_indices, void *out_data,
+                   void *out_eta, uint8_t *out_sel, void *stream) {
+    if (n < 0 || !indptr || !ab || (n > 0 && !out_indices))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr_ab: NULL pointer or negative n");
+    if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_topk_csr_ab: k=%d outside 1..%d", k, XC_MAX_K);
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_topk_csr_ab: unknown dtype %d", dtype);
+    const int ch = xc::chunks_for(max_row_nnz);
+    if (ch == 0)
+        return xc::fail_arg(XC_ERR_ROW_TOO_LONG, "xc_topk_csr_ab: a row holds %d entries, limit %d", max_row_nnz, XC_MAX_ROW_NNZ);
+    if (n == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32 && max_row_nnz <= 64 && n < (1 << 24) && !xc::g_topk_one_row_per_wave)
+        xc::launch_topk_q4(n, indptr, indices, data, k, ab, nullptr, -1, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, st);
+    else if (dtype == XC_F32)
+        xc::launch_topk<float>(n, indptr, indices, data, k, ab, nullptr, -1, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
+    else
+        xc::launch_topk<double>(n, indptr, indices, data, k, ab, nullptr, -1, nullptr, keep_scores, out_indices, out_data, out_eta, out_sel, ch, st);
+    XC_CHECK_LAUNCH("topk_csr_kernel (ab)");
+    return XC_OK;
 }
 
 // ---- one weighted classifier per row (frank_wolfe.py:127-172) ----

@@ -185,7 +185,12 @@ class FwEngine:
             a_d = D.to_device(a, dtype=self.weight_dtype, device=self.dev)
             b_d = D.to_device(b, dtype=self.weight_dtype, device=self.dev)
             if self.k > 0:
-                idx, _, _ = topk_csr_device(self.proba, self.k, a_d, b_d)
+                # {a, b} interleaved: one gather per candidate (same gains bit for bit)
+                ab = torch.stack((a_d, b_d), dim=1).contiguous()
+                idx = torch.empty(self.n * self.k, dtype=torch.int32, device=self.dev)
+                c = self.proba
+                _lib.call("xc_topk_csr_ab", c.n, D.ptr(c.indptr), D.ptr(c.indices), D.ptr(c.data), c.code,
+                          int(c.max_row_nnz), self.k, D.ptr(ab), 0, D.ptr(idx), None, None, None, D.stream())
                 pred = D.DeviceCSR(self._pred_indptr, idx, self._pred_ones, (self.n, self.m), self.k)
             else:
                 indptr, idx = threshold_csr_device(self.proba, 0.0, a_d, b_d)
