@@ -58,10 +58,11 @@ __device__ __forceinline__ FastD nsqrt(FastD a) { return FastD(sqrt(a.v)); }
 
 // metrics.py formulas in the reference's operation order (the file is compiled with
 // -ffp-contract=off), for N = double or Dual
-template <typename N>
+// BASE >= 0 fixes the formula at compile time (the step scan's inner loop), -1 reads mt.base
+template <typename N, int BASE = -1>
 __device__ __forceinline__ N fw_base(const xc_metric &mt, N tp, N fp, N fn, N tn) {
     const double eps = mt.epsilon;
-    switch (mt.base) {
+    switch (BASE >= 0 ? BASE : mt.base) {
     case XC_M_PRECISION_AT_K: return tp / N(mt.kf);                       // :513
     case XC_M_PRECISION: return tp / (tp + fp + N(eps));                   // :605
     case XC_M_RECALL: return tp / (tp + fn + N(eps));                      // :652
@@ -92,9 +93,9 @@ __device__ __forceinline__ N fw_base(const xc_metric &mt, N tp, N fp, N fn, N tn
     }
 }
 
-template <typename N>
+template <typename N, int BASE = -1>
 __device__ __forceinline__ N fw_metric(const xc_metric &mt, N tp, N fp, N fn, N tn) {
-    N v = fw_base<N>(mt, tp, fp, fn, tn);
+    N v = fw_base<N, BASE>(mt, tp, fp, fn, tn);
     if (mt.mixed) // frank_wolfe.py:832-838
         v = N(1.0 - mt.alpha) * (tp / N(mt.kf)) + (N(mt.alpha) * v) / N(mt.mf);
     return v;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(XC_BLOCK) void fw_gradient_kernel(int64_t m, const 
 // EXACT: the reference's expression and IEEE division (two-point ternary steps).  Otherwise (the
 // 10^4-point uniform scan, VALU-bound): the mix as one fma per entry, cur + alpha * (nxt - cur), and
 // the ~1-ulp division -- differences of the size of the summation-order ones.
-template <bool EXACT>
+template <bool EXACT, int BASE>
 __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, const double *cur, const double *nxt,
                                                                    xc_metric metric, int n_alpha,
                                                                    const double *alphas, int64_t per_chunk,
@@ -158,13 +159,13 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
                     const double fp = keep * s_cur[i][1] + alpha * s_nxt[i][1];
                     const double fn = keep * s_cur[i][2] + alpha * s_nxt[i][2];
                     const double tn = keep * s_cur[i][3] + alpha * s_nxt[i][3];
-                    sum += fw_metric<double>(metric, tp, fp, fn, tn);
+                    sum += fw_metric<double, BASE>(metric, tp, fp, fn, tn);
                 } else {
                     const FastD tp(__builtin_fma(alpha, s_nxt[i][0], s_cur[i][0]));
                     const FastD fp(__builtin_fma(alpha, s_nxt[i][1], s_cur[i][1]));
                     const FastD fn(__builtin_fma(alpha, s_nxt[i][2], s_cur[i][2]));
                     const FastD tn(__builtin_fma(alpha, s_nxt[i][3], s_cur[i][3]));
-                    sum += fw_metric<FastD>(metric, tp, fp, fn, tn).v;
+                    sum += fw_metric<FastD, BASE>(metric, tp, fp, fn, tn).v;
                 }
             }
         }
@@ -204,12 +205,32 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_
     const int64_t tiles = (m + XC_FW_TILE - 1) / XC_FW_TILE;
     const int64_t per_chunk = ((tiles + chunks - 1) / chunks) * XC_FW_TILE;
     const int gx = (n_alpha + XC_FW_TILE - 1) / XC_FW_TILE;
-    if (n_alpha <= XC_FW_EXACT_POINTS)
-        hipLaunchKernelGGL(xc::fw_alpha_curve_kernel<true>, dim3(gx, chunks), dim3(XC_FW_TILE), 0, xc::as_stream(stream),
-                           m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials);
-    else
-        hipLaunchKernelGGL(xc::fw_alpha_curve_kernel<false>, dim3(gx, chunks), dim3(XC_FW_TILE), 0, xc::as_stream(stream),
-                           m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials);
+    hipStream_t st = xc::as_stream(stream);
+    if (n_alpha <= XC_FW_EXACT_POINTS) {
+        hipLaunchKernelGGL((xc::fw_alpha_curve_kernel<true, -1>), dim3(gx, chunks), dim3(XC_FW_TILE), 0, st, m, cur, nxt,
+                           *metric_host, n_alpha, alphas, per_chunk, partials);
+    } else {
+        // the long scan is float64-VALU-bound: the formula is fixed at compile time so the inner loop
+        // carries no switch
+#define XC_FW_SCAN(B)                                                                                              \
+    case B:                                                                                                        \
+        hipLaunchKernelGGL((xc::fw_alpha_curve_kernel<false, B>), dim3(gx, chunks), dim3(XC_FW_TILE), 0, st, m, cur, \
+                           nxt, *metric_host, n_alpha, alphas, per_chunk, partials);                               \
+        break
+        switch (metric_host->base) {
+            XC_FW_SCAN(XC_M_PRECISION_AT_K);
+            XC_FW_SCAN(XC_M_PRECISION);
+            XC_FW_SCAN(XC_M_RECALL);
+            XC_FW_SCAN(XC_M_FBETA);
+            XC_FW_SCAN(XC_M_JACCARD);
+            XC_FW_SCAN(XC_M_BALANCED_ACC);
+            XC_FW_SCAN(XC_M_GMEAN);
+            XC_FW_SCAN(XC_M_HMEAN);
+            XC_FW_SCAN(XC_M_ACCURACY);
+            XC_FW_SCAN(XC_M_RECALL_PRECISION_MIX);
+        }
+#undef XC_FW_SCAN
+    }
     XC_CHECK_LAUNCH("fw_alpha_curve_kernel");
     return XC_OK;
 }
