@@ -95,6 +95,50 @@ def test_topk_dense_golden(tag, kind):
     assert np.array_equal(back(predict_weighted_per_instance(Yin, 0, th=th)), z["pred_k0_plain"])
 
 
+@pytest.mark.parametrize("k", [1, 5, 17, 64])
+def test_topk_csr_short_rows_adversarial_vs_oracle(oref, k):
+    """float32 rows of at most 64 entries take the four-rows-per-wavefront kernel: rows of every length
+    0..64 (so k > r, k == r, k < r all occur), heavily tied scores (values on a grid of 8: the lowest
+    column must win), negative and zero weights, +-inf and NaN gains, keep_scores, eta / sel outputs of
+    the BCA initialisation.  Index sets must be identical to the oracle's."""
+    from xcolumns_amd import _device as D
+    from xcolumns_amd.weighted_prediction import predict_weighted_per_instance, topk_csr_device
+    rng = np.random.default_rng(100 + k)
+    n, m = 4099, 500   # not a multiple of 4 rows per wave
+    lens = rng.integers(0, 65, size=n)
+    lens[:65] = np.arange(65)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = np.concatenate([np.sort(rng.choice(m, r, replace=False)) for r in lens]).astype(np.int32)
+    data = (rng.integers(0, 8, size=cols.size) / 8.0).astype(np.float32)      # ties everywhere
+    Y = csr_matrix((data, cols, indptr), shape=(n, m))
+    a = rng.normal(size=m).astype(np.float32)
+    a[::7] = 0.0
+    b = rng.normal(size=m).astype(np.float32)
+    b[3], b[11], b[19] = np.inf, -np.inf, np.nan
+    for kw in (dict(), dict(a=a, b=b), dict(a=a), dict(b=b, keep_scores=True)):
+        Pg = predict_weighted_per_instance(Y, k, **kw)
+        Po = oref.predict_weighted_per_instance(Y, k, **kw)
+        _same_csr(Pg, Po, data_exact=False)
+        if kw.get("keep_scores"):
+            assert np.array_equal(Pg.data, Po.data, equal_nan=True)
+    # the BCA initialisation outputs (eta of the chosen entries, per-entry flags); rows need >= k entries
+    keep = lens >= k
+    Yk = Y[keep]
+    csr = D.DeviceCSR.from_scipy(Yk, D.require_gpu())
+    sel = torch.zeros(csr.nnz, dtype=torch.uint8, device="cuda")
+    idx, dat, eta = topk_csr_device(csr, k, want_eta=True, out_sel=sel)
+    Po = oref.predict_top_k(Yk, k)
+    assert np.array_equal(idx.cpu().numpy(), Po.indices)
+    dense = Yk.toarray()
+    rows = np.repeat(np.arange(Yk.shape[0]), k)
+    assert np.array_equal(eta.cpu().numpy(), dense[rows, Po.indices])
+    flags = sel.cpu().numpy()
+    assert flags.sum() == Yk.shape[0] * k
+    chosen = csr_matrix((flags.astype(np.float32), Yk.indices, Yk.indptr), shape=Yk.shape)
+    chosen.eliminate_zeros()
+    assert np.array_equal(chosen.indices, Po.indices)
+
+
 def test_topk_csr_long_rows_vs_oracle(oref):
     """Rows of up to 1000 entries (the *_1000_* prediction files of the reference's
     experiments) exercise the multi-chunk register path; oracle is the checker."""

@@ -139,14 +139,16 @@ __device__ __forceinline__ unsigned long long wave_umin64(unsigned long long v) 
 // Order-preserving map from float64 to uint64 (larger gain -> larger key).  NaN
 // was mapped to -inf before.  Every finite/infinite double maps to a key >= 1
 // (-inf -> 0x000fffffffffffff), so key 0 marks "no candidate".
+// -0.0 and +0.0 compare equal in the reference's numpy selection (a tie: the lower column
+// wins), so both map to the key of +0.0 (x + 0.0 turns -0.0 into +0.0 and nothing else).
 __device__ __forceinline__ unsigned long long sortable_key(double g) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(g);
+    const unsigned long long u = (unsigned long long)__double_as_longlong(g + 0.0);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
 // float32 flavour: every non-NaN float maps to a key >= 1 (0 = no candidate)
 __device__ __forceinline__ unsigned sortable_key32(float g) {
-    const unsigned u = __float_as_uint(g);
+    const unsigned u = __float_as_uint(g + 0.0f);
     return (u >> 31) ? ~u : (u | 0x80000000u);
 }
 
