@@ -139,6 +139,25 @@ def test_topk_csr_short_rows_adversarial_vs_oracle(oref, k):
     assert np.array_equal(chosen.indices, Po.indices)
 
 
+@pytest.mark.parametrize("m", [1, 255, 257, 1000, 4097, 8192, 9000])
+def test_topk_dense_adversarial_vs_oracle(oref, m):
+    """Dense rows of float32 gains: register-resident kernel up to 8192 labels, the streaming one beyond;
+    tied scores on a coarse grid (lowest column wins), -0.0 / +0.0, +-inf and NaN, k >= m."""
+    from xcolumns_amd.weighted_prediction import predict_weighted_per_instance
+    rng = np.random.default_rng(m)
+    n = 67
+    Y = (rng.integers(-4, 5, size=(n, m)) / 4.0).astype(np.float32)
+    Y[Y == 0] = np.where(rng.random((Y == 0).sum()) < 0.5, -0.0, 0.0)
+    if m > 10:
+        Y[3, 5], Y[3, 7], Y[4, 2], Y[5, :4] = np.inf, -np.inf, np.nan, np.nan
+    for k in sorted({1, min(5, m), min(64, m), m if m <= 1000 else min(300, m)}):
+        for keep in (False, True):
+            Pg = predict_weighted_per_instance(Y, k, keep_scores=keep)
+            Po = oref.predict_weighted_per_instance(Y, k, keep_scores=keep)
+            assert Pg.dtype == Y.dtype and Pg.shape == Y.shape
+            assert np.array_equal(Pg, Po, equal_nan=True), (m, k, keep, np.argwhere(~((Pg == Po) | (np.isnan(Pg) & np.isnan(Po))))[:5])
+
+
 def test_topk_csr_long_rows_vs_oracle(oref):
     """Rows of up to 1000 entries (the *_1000_* prediction files of the reference's
     experiments) exercise the multi-chunk register path; oracle is the checker."""
