@@ -714,3 +714,35 @@ def test_bca_dense_concurrent_vs_oracle(oref, dtype, k, skip_tn, entry):
     assert abs(u - mg["utilities"][-1]) < 1e-12
     Pe, me = getattr(bc, entry)(Y, k, seed=13, max_iters=4, tolerance=-1.0, return_meta=True, bca_waves=1)
     assert np.allclose(me["utilities"], mo["utilities"], rtol=0, atol=1e-12) and np.array_equal(Pe, Po)
+
+
+@pytest.mark.parametrize("init", ["greedy", "random", "matrix_with_foreign_labels"])
+def test_pipelined_loop_after_a_host_paced_first_sweep(oref, init):
+    """Greedy first sweeps and initial predictions holding labels a row does not store cannot use the
+    device-side loop for sweep 1; the loop switches over from sweep 2.  Same bars as the other
+    concurrent runs against the sequential oracle."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    from xcolumns_amd.synthetic import make_csr
+
+    n, m, k = 20000, 2000, 4
+    Y = make_csr(n, m, 30, seed=91, k=k)
+    kw = dict(seed=13, max_iters=5, tolerance=-1.0)
+    if init == "matrix_with_foreign_labels":
+        rng = np.random.default_rng(5)
+        idx = np.sort(np.stack([rng.choice(m, k, replace=False) for _ in range(n)]), axis=1).astype(np.int32)
+        mk = lambda: csr_matrix((np.ones(n * k, dtype=np.float32), idx.ravel().copy(), np.arange(n + 1, dtype=np.int32) * k),
+                                shape=(n, m))
+        init_o, init_g = mk(), mk()
+    else:
+        init_o = init_g = init
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, init_y_pred=init_o, **kw)
+    Pg, mg = predict_optimizing_macro_f1_score_using_bc(Y, k, init_y_pred=init_g, return_meta=True, **kw)
+    assert mg["iters"] == mo["iters"] == 5
+    diff = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print(init, "concurrent-vs-sequential utility diff per sweep:", diff)
+    assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL, (mg["utilities"], mo["utilities"])
+    tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, Pg, skip_tn=True)
+    assert abs(oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n) - mg["utilities"][-1]) < 1e-12
+    if init == "matrix_with_foreign_labels":
+        assert Pg is init_g   # updated in place and returned, like the reference

@@ -84,9 +84,14 @@ class WavePolicy:
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
 
-    def next(self, changed_prev: Optional[int] = None) -> int:
+    def next(self, changed_prev: Optional[int] = None, greedy: bool = False) -> int:
+        """`greedy`: the first sweep of init_y_pred="greedy" -- every row is added to statistics that
+        start from zero and no row is validated, which measures ~16x the difference per row in flight
+        (5.6e-4 at the ordinary width, C2 shape): it runs 16x narrower, on every rank."""
         if self.fixed:
             return max(1, min(self.fixed, self.n))
+        if greedy:
+            return int(max(1, min(self.cap, self.n, self.budget * self.n / 16)))
         if self.world > 1:
             # rows of the other ranks are invisible within a sweep whatever W is
             # (DESIGN.md section 7): bounding this rank's own concurrency buys nothing
@@ -474,7 +479,7 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
 
         log_info("    Doing block coordinate optimization steps ...", verbose)
         eng.reset_changed()
-        n_waves = policy.next(changed_prev)
+        n_waves = policy.next(changed_prev, greedy=True) if greedy else policy.next(changed_prev)
         eng.sweep(order, n_order, n_waves, greedy=greedy)
         if greedy:
             eng.sync_column_sums()

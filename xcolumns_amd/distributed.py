@@ -146,7 +146,7 @@ class _FixedWaves:
     def __init__(self, w):
         self.w = int(w)
 
-    def next(self, changed_prev=None):
+    def next(self, changed_prev=None, greedy=False):
         return self.w
 
 
