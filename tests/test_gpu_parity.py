@@ -746,3 +746,24 @@ def test_pipelined_loop_after_a_host_paced_first_sweep(oref, init):
     assert abs(oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n) - mg["utilities"][-1]) < 1e-12
     if init == "matrix_with_foreign_labels":
         assert Pg is init_g   # updated in place and returned, like the reference
+
+
+@pytest.mark.parametrize("k", [33, 64])
+def test_bca_csr_large_budget(oref, k):
+    """Budgets above 32 labels per row (XC_MAX_K = 64): the from-scratch statistics a sweep accumulates
+    carry 32 predicted entries per deferred wave instruction, the rest separately.  Exact mode reproduces
+    the oracle; the concurrent default stays within the bars and reports the utility of what it returns."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    rng = np.random.default_rng(k)
+    n, m, r = 6000, 900, 100
+    cols = np.concatenate([np.sort(rng.choice(m, r, replace=False)) for _ in range(n)]).astype(np.int32)
+    Y = csr_matrix(((rng.random(n * r) ** 3).astype(np.float32), cols, (np.arange(n + 1) * r).astype(np.int32)), shape=(n, m))
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=2, max_iters=8, tolerance=-1.0)
+    Pe, me = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=2, max_iters=8, tolerance=-1.0, return_meta=True, bca_waves=1)
+    assert np.allclose(me["utilities"], mo["utilities"], rtol=0, atol=1e-12) and np.array_equal(Pe.indices, Po.indices)
+    Pg, mg = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=2, max_iters=8, tolerance=-1.0, return_meta=True)
+    diff = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL, (mg["utilities"], mo["utilities"])
+    tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, Pg, skip_tn=True)
+    assert abs(oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n) - mg["utilities"][-1]) < 1e-12

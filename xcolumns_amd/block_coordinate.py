@@ -64,34 +64,37 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 # and the difference heals in the following sweeps.  The default keeps that
 # product below XCOLUMNS_BCA_STALE_BUDGET for every sweep, using the previous
 # sweep's number of changed rows (n/2 before the first): W grows as the
-# optimisation converges, so late sweeps use the whole GPU.
+# optimisation converges, so late sweeps use the whole GPU.  The constant was measured at the
+# benchmark's budget k = 5; a changing row moves more labels the larger k is and the trajectories
+# then settle in different, nearly equivalent optima (k = 64, n = 6000: 1.6e-4 in sweep 1 at the
+# k = 5 width, 1-4e-5 left after 8 sweeps at 1/13 of it), so the budget is scaled by (5 / k)^1.5.
 _STALE_BUDGET = float(os.environ.get("XCOLUMNS_BCA_STALE_BUDGET", "4e-3"))
-_MIN_WAVES = 16
+_MIN_WAVES = 1
 
 
 class WavePolicy:
     """Number of concurrent wavefronts for the next sweep."""
 
     def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None,
-                 world: int = 1):
+                 world: int = 1, k: int = 5):
         """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows
-        (the changed-row count fed to :meth:`next` is the global one)."""
+        (the changed-row count fed to :meth:`next` is the global one); `k`: labels per row."""
         self.world = max(1, int(world))
         env = os.environ.get("XCOLUMNS_BCA_WAVES")
         self.fixed = int(fixed) if fixed else (int(env) if env else None)
         self.n = max(1, int(n_order))
-        self.budget = _STALE_BUDGET if budget is None else float(budget)
+        self.budget = (_STALE_BUDGET if budget is None else float(budget)) * min(1.0, 5.0 / max(1, int(k))) ** 1.5
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
 
     def next(self, changed_prev: Optional[int] = None, greedy: bool = False) -> int:
         """`greedy`: the first sweep of init_y_pred="greedy" -- every row is added to statistics that
-        start from zero and no row is validated, which measures ~16x the difference per row in flight
-        (5.6e-4 at the ordinary width, C2 shape): it runs 16x narrower, on every rank."""
+        start from zero and no row is validated, which measures ~0.2 * W / n (5.6e-4 at the ordinary
+        width, C2 shape): it runs 32x narrower, on every rank."""
         if self.fixed:
             return max(1, min(self.fixed, self.n))
         if greedy:
-            return int(max(1, min(self.cap, self.n, self.budget * self.n / 16)))
+            return int(max(1, min(self.cap, self.n, self.budget * self.n / 32)))
         if self.world > 1:
             # rows of the other ranks are invisible within a sweep whatever W is
             # (DESIGN.md section 7): bounding this rank's own concurrency buys nothing
@@ -576,7 +579,7 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
         eng.init_indices(torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)))
 
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
-    policy = WavePolicy(n_u, fixed=bca_waves)
+    policy = WavePolicy(n_u, fixed=bca_waves, k=k)
     run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                    policy, verbose, meta)
 
@@ -653,7 +656,7 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
     # rows in flight: the CSR policy (one workgroup here = one "wavefront" there), bounded by the
     # workgroups the GPU holds; bca_waves=1 is the reference's sequential sweep
-    policy = WavePolicy(n_u, fixed=bca_waves)
+    policy = WavePolicy(n_u, fixed=bca_waves, k=max(1, k))
     max_blocks = max(1, policy.cap // _DENSE_BLOCK_WAVES)
     changed = torch.zeros(1, dtype=torch.int64, device=dev)
     changed_prev = None

@@ -516,11 +516,23 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            pend_n = nsel;
+            // one deferred wave instruction carries 32 predicted entries (two lanes each) ...
+            pend_n = nsel < XC_WAVE / 2 ? nsel : XC_WAVE / 2;
             const int q = (lane >> 1) < nsel ? (lane >> 1) : 0;
             pend_idx = s_pack_idx[wib][q];
             const T e = s_pack_eta[wib][q];
             pend_val = (lane & 1) ? (double)((T)1 - e) : (double)e;
+            // ... the rest (budgets k > 32 only) goes out at once
+            for (int q0 = XC_WAVE / 2; q0 < nsel; q0 += XC_WAVE / 2) {
+                const int q2 = q0 + (lane >> 1);
+                if (q2 < nsel) {
+                    const T e2 = s_pack_eta[wib][q2];
+#ifndef XC_EXP_SKIP_ACC
+                    atomic_add_f64(P.acc + (int64_t)s_pack_idx[wib][q2] * 2 + (lane & 1),
+                                   (lane & 1) ? (double)((T)1 - e2) : (double)e2);
+#endif
+                }
+            }
         }
         if (row_changed || greedy) {
             int base = 0;

@@ -130,7 +130,7 @@ def predict_bca_csr_sharded(
         return to_dev(local_order(order, lo, hi))
 
     meta = {"utilities": [], "iters": 0, "time": time()}
-    policy = (bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world) if engine_factory is None
+    policy = (bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world, k=k) if engine_factory is None
               else _FixedWaves(bca_waves or 1))
     bc.run_bca_sweeps(eng, next_order, n_local, n_total, m, metric_aggregation, maximize, tolerance, max_iters,
                       False, policy, verbose, meta)
