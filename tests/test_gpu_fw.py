@@ -183,3 +183,38 @@ def test_frank_wolfe_api_contract():
     macro_f1_score_on_conf_matrix.__module__ = "xcolumns.metrics"
     clf2 = xfw.find_classifier_using_fw(Yt, Yp, macro_f1_score_on_conf_matrix, 3, max_iters=3, skip_tn=True)
     np.testing.assert_array_equal(clf2.a, clf.a)
+
+
+def test_frank_wolfe_ragged_rows_vs_oracle():
+    """Rows shorter than k (the weighted top-k pads them with column 0, duplicated: SURVEY a-10 i) and
+    empty rows go through the same confusion arithmetic as the reference's numba kernels."""
+    from oracle import fw_ref as fw
+
+    import xcolumns_amd.frank_wolfe as xfw
+    import xcolumns_amd.metrics as xm
+
+    rng = np.random.default_rng(8)
+    n, m, k = 4000, 120, 5
+    lens = rng.integers(0, 21, size=n)
+    lens[:6] = np.arange(6)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = np.concatenate([np.sort(rng.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
+    w = 0.05 + 0.95 * rng.random(m) ** 2
+    eta = ((rng.random(cols.size) ** 2) * w[cols]).astype(np.float64)
+    Yp = csr_matrix((eta, cols, indptr), shape=(n, m))
+    Yt = csr_matrix(((rng.random(cols.size) < eta).astype(np.float64), cols.copy(), indptr.copy()), shape=(n, m))
+    Yt.eliminate_zeros()
+    for avg, metric in (("macro", "f1_score"), ("micro", "precision")):
+        A, B, P, meta_o = fw.find_classifier_using_fw(Yt, Yp, fw.FwMetric(base=getattr(fw, G.FW_STEMS[metric]), average=avg),
+                                                     k, max_iters=5, skip_tn=True, alpha_uniform_search_step=0.001)
+        clf, meta = xfw.find_classifier_using_fw(Yt, Yp, getattr(xm, f"{avg}_{metric}_on_conf_matrix"), k, max_iters=5,
+                                                 skip_tn=True, alpha_uniform_search_step=0.001, return_meta=True)
+        assert meta["iters"] == meta_o["iters"]
+        np.testing.assert_array_equal(np.asarray(meta["alphas"], dtype=np.float64), np.asarray(meta_o["alphas"]))
+        np.testing.assert_allclose(meta["utilities"], meta_o["utilities"], rtol=1e-12)
+        np.testing.assert_array_equal(clf.p, P)
+        pred = clf.predict(Yp, seed=4)
+        pred_o = fw.predict_using_randomized_weighted_classifier(Yp, k, clf.a, clf.b, clf.p, seed=4)
+        np.testing.assert_array_equal(pred.indptr, pred_o.indptr)
+        np.testing.assert_array_equal(pred.indices, pred_o.indices)
+        assert (np.diff(pred.indptr) == np.minimum(lens, k)).all()
