@@ -122,6 +122,7 @@ def main():
     csr = D.DeviceCSR.from_scipy(Y, dev)
     spec = MetricSpec(base=_lib.XC_M_FBETA)  # macro-F1: binary_f1_score_on_conf_matrix, eps 1e-9
     eng = BcaCsrEngine(csr, K, spec, spec, maximize=True, skip_tn=True, n_total=n * world, comm=comm)
+    policy = WavePolicy(n, fixed=args.waves if args.waves > 0 else None, world=world, k=K)   # as _bc_csr builds it
     n_u = n * world   # normalisation of the utility = global row count
 
     # visiting orders of every sweep, the reference's RNG stream (seed 13), uploaded up front
@@ -133,7 +134,6 @@ def main():
         rng.shuffle(order)
         orders[s] = torch.from_numpy(order.astype(np.int32)).to(dev)
 
-    policy = WavePolicy(n, fixed=args.waves if args.waves > 0 else None, world=world)
     eng.init_top()
     eng.reset_state(greedy=False)
     u0 = eng.recompute_utility_sum(n_u) / m
