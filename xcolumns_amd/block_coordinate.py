@@ -768,6 +768,8 @@ def predict_using_bc_with_0approx(
     utility_spec = resolve_metric(binary_metric_func, None)
 
     n, m = y_proba.shape
+    if n == 0 or m == 0:
+        raise ValueError(f"y_proba must have at least one row and one column, got shape {tuple(y_proba.shape)}")
     n_u = n if normalize_conf_matrix else 1   # :403-405 (also the length of the visiting order, :414)
 
     bca_waves = kwargs.pop("bca_waves", None)
