@@ -370,8 +370,9 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
 /* Arm the control block: `old_utility_sum` = utility sum of the current prediction;
  * the rule is (new/divisor - old/divisor < tolerance) for maximize, (> tolerance)
  * otherwise (divisor = m for metric_aggregation "mean", 1 for "sum").  Wavefronts of
- * the next sweep = fixed_waves if > 0, else max_waves when world > 1, else
- * clamp(floor(policy_num / max(1, changed / world)), min_waves, max_waves);
+ * the next sweep = fixed_waves if > 0, else
+ * clamp(floor(policy_num / max(1, changed / world)), min_waves, max_waves) (changed = rows
+ * changed over all ranks);
  * `first_waves` is used by the first sweep. */
 int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance, double divisor,
                           int maximize, double policy_num, int world, int min_waves,

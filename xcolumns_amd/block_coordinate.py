@@ -95,10 +95,8 @@ class WavePolicy:
             return max(1, min(self.fixed, self.n))
         if greedy:
             return int(max(1, min(self.cap, self.n, self.budget * self.n / 32)))
-        if self.world > 1:
-            # rows of the other ranks are invisible within a sweep whatever W is
-            # (DESIGN.md section 7): bounding this rank's own concurrency buys nothing
-            return int(max(1, min(self.cap, self.n)))
+        # sharded rows: the other ranks' updates are invisible within a sweep whatever W is (DESIGN.md
+        # section 7), but this rank's own rows still follow the budget, on its share of the changes
         changed = self.n / 2 if changed_prev is None else max(1.0, changed_prev / self.world)
         want = int(self.budget * self.n * self.n / changed)
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))

@@ -826,8 +826,6 @@ __global__ __launch_bounds__(XC_UTILITY_PARTIALS / 2) void bca_boundary_finish_k
     double w;
     if (ctrl[XC_CTRL_FIXED_WAVES] > 0.0) {
         w = ctrl[XC_CTRL_FIXED_WAVES];
-    } else if (ctrl[XC_CTRL_WORLD] > 1.0) {
-        w = max_w;
     } else {
         double c = changed / ctrl[XC_CTRL_WORLD];
         if (c < 1.0) c = 1.0;
