@@ -378,10 +378,13 @@ int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance
                           int maximize, double policy_num, int world, int min_waves,
                           int max_waves, int fixed_waves, int first_waves, void *stream);
 
-/* A full, non-greedy sweep over `order` (xc_bca_plan_sweep with acc), launched for
- * max_waves wavefronts; runs only if the stop flag is clear, with ctrl's count. */
-int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed, int max_waves,
-                                const double *ctrl, void *stream);
+/* Positions [first, first + count) of a full, non-greedy sweep over `order`
+ * (xc_bca_plan_sweep with acc), launched for max_waves wavefronts; runs only if the
+ * stop flag is clear, with ctrl's count.  A sweep is one call with (0, n) or several
+ * consecutive segments that together cover the order (sharded rows: the ranks exchange
+ * their changes between segments); `acc` is complete after the last one. */
+int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int64_t first, int64_t count,
+                                int use_packed, int max_waves, const double *ctrl, void *stream);
 
 /* The boundary after it (the caller all-reduces acc in between when rows are
  * sharded): commit + utility partials, then the rule and the policy on the GPU; the

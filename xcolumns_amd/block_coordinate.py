@@ -182,6 +182,9 @@ class BcaCsrEngine:
                 self.hot_slot[labels.long()] = torch.arange(1, n_hot + 1, dtype=torch.uint8, device=dev)
         # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count
         self.acc = torch.zeros(2 * m + 1, dtype=torch.float64, device=dev)
+        # sharded rows: exchanges of the ranks' changes per sweep (1 = only the all-reduce of the
+        # from-scratch statistics at the sweep boundary, the north-star scheme)
+        self.exchanges = max(1, int(os.environ.get("XCOLUMNS_BCA_EXCHANGES", "1")))
         self._acc_filled = False    # did the last sweep leave the new prediction's statistics in acc
         self._changed_last = 0
         self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=dev)
@@ -357,8 +360,32 @@ class BcaCsrEngine:
         if self.packed is not None and self._pack_dirty:
             self._repack()
         use_packed = self.packed is not None
-        _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), int(use_packed),
-                  int(self._pipe_max_waves), D.ptr(self._ctrl), D.stream())
+        n = self.csr.n
+        segments = self.exchanges if (self.comm is not None and self.shadow is not None) else 1
+        if segments <= 1:
+            _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), 0, n, int(use_packed),
+                      int(self._pipe_max_waves), D.ptr(self._ctrl), D.stream())
+        else:
+            # Sharded rows, several exchanges per sweep (XCOLUMNS_BCA_EXCHANGES / bca_exchanges): the
+            # order is walked in `segments` parts; between two parts every rank publishes what its rows
+            # changed in the float32 records since the last exchange and takes in the others' changes,
+            # so a rank misses the other ranks' updates of 1/segments of a sweep instead of a whole one.
+            if order is None:
+                order = torch.arange(n, dtype=torch.int32, device=self.dev)
+            if getattr(self, "_snap", None) is None:
+                self._snap = torch.empty_like(self.shadow)
+            self._snap.copy_(self.shadow)
+            bounds = [n * s // segments for s in range(segments + 1)]
+            for s in range(segments):
+                _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), bounds[s],
+                          bounds[s + 1] - bounds[s], int(use_packed), int(self._pipe_max_waves), D.ptr(self._ctrl),
+                          D.stream())
+                if s < segments - 1:
+                    mine = self.shadow - self._snap
+                    everyone = mine.clone()
+                    self.comm.all_reduce(everyone)
+                    self.shadow += everyone - mine
+                    self._snap.copy_(self.shadow)
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
         slot = j % _lib.XC_CTRL_RING_SLOTS

@@ -1237,12 +1237,14 @@ int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance
     return XC_OK;
 }
 
-int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int use_packed, int max_waves, const double *ctrl,
-                                void *stream) {
+int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int64_t first, int64_t count, int use_packed,
+                                int max_waves, const double *ctrl, void *stream) {
     if (!plan || !ctrl || max_waves < 2)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep_pipelined: bad argument");
     const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
-    return sweep_csr_impl(p->n, order, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
+    if (first < 0 || count < 0 || first + count > p->n || (!order && (first != 0 || count != p->n)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep_pipelined: bad segment (a partial segment needs `order`)");
+    return sweep_csr_impl(count, order ? order + first : nullptr, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
                           p->pred_indices, p->pred_eta, p->sel, nullptr, p->k, p->m, p->tpfp, p->shadow, p->colsum,
                           p->s_entry, use_packed ? p->packed : nullptr, p->hot_labels, p->acc, &p->gain_metric,
                           p->maximize, 0, p->skip_tn, max_waves, nullptr, ctrl, stream);

@@ -77,6 +77,7 @@ def predict_bca_csr_sharded(
     seed: Optional[int] = None,
     verbose: bool = False,
     bca_waves: Optional[int] = None,
+    bca_exchanges: Optional[int] = None,
     engine_factory=None,
 ):
     """BCA (init "top") with the rows sharded over the ranks of `comm`: every rank
@@ -87,7 +88,11 @@ def predict_bca_csr_sharded(
     (``np.random.default_rng(seed)``, block_coordinate.py:413-419) over the global
     row ids, restricted to the rank's block (:func:`local_order`).
     `engine_factory(csr_shard, k, gain_spec, utility_spec, maximize, skip_tn, n_total,
-    comm)` builds the per-rank engine; the default is the GPU engine."""
+    comm)` builds the per-rank engine; the default is the GPU engine.
+    `bca_exchanges` (default 1, env XCOLUMNS_BCA_EXCHANGES): how often per sweep the ranks
+    exchange what their rows changed; 1 = only the all-reduce of the from-scratch statistics
+    at the sweep boundary, S > 1 = S - 1 more all-reduces of the float32 records (8 bytes per
+    label) inside the sweep, which cuts the cross-rank staleness about S-fold."""
     from time import time
 
     from . import block_coordinate as bc
@@ -114,6 +119,8 @@ def predict_bca_csr_sharded(
         csr = D.DeviceCSR.from_scipy(y_proba_shard, dev)
         eng = bc.BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
                               n_total=n_total, comm=comm)
+        if bca_exchanges:
+            eng.exchanges = max(1, int(bca_exchanges))
         to_dev = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
     else:
         eng = engine_factory(y_proba_shard, k, gain_spec, utility_spec, maximize, skip_tn, n_total, comm)
