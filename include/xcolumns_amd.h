@@ -78,8 +78,9 @@ typedef struct xc_metric {
  *                          so far (constant during a non-greedy sweep);
  *   s_entry float64[nnz]   colsum expanded per stored entry of y_proba, so it
  *                          streams in with the row instead of being gathered.
- *   packed  16 B x nnz     optional (float32 scores): {col | sel << 31, eta, s} per
- *                          stored entry -- indices, data, sel and s_entry interleaved,
+ *   packed  16 B x nnz     optional (float32 scores, m <= 2^25): {col | hot << 25 |
+ *                          sel << 31, eta, s} per stored entry -- indices, data, sel and
+ *                          s_entry (and the label's hot slot, 0 = none) interleaved,
  *                          so a candidate streams in as ONE 16-byte lane load
  *                          (xc_bca_pack_rows; the sweep keeps its sel bits current).
  *   shadow  float32[m][2]  optional rounded copy of tpfp (8-byte records): what the
