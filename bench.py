@@ -283,7 +283,7 @@ def main():
             "utility_first_last": [utilities[0], utilities[-1]],
             "utility_top_k": u0,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(Y, K, seed=13)
         print(json.dumps(out))
     if world > 1:
