@@ -158,3 +158,21 @@ def fw_oracle_call(fw, z, spec):
     if spec["init_ab"]:
         kw["init_classifier"] = (z["init_a"], z["init_b"])
     return fw.find_classifier_using_fw(y_true, y_proba, metric, k, **kw)
+
+
+# ---------------------------------------------------------------------------
+# coverage BCA fixtures (tests/golden/coverage.npz)
+# ---------------------------------------------------------------------------
+
+def coverage_cases(z):
+    return [json.loads(str(s)) for s in z["specs"]]
+
+
+def coverage_inputs(z, ci, spec):
+    Y = csr_from(z, "y_" + spec["dtype"])
+    kw = dict(spec["kwargs"])
+    if spec["explicit_init"]:
+        n, k = Y.shape[0], spec["k"]
+        kw["init_y_pred"] = csr_matrix((np.ones(n * k, dtype=Y.dtype), z[f"c{ci}_init_indices"].copy(),
+                                        (np.arange(n + 1) * k).astype(Y.indptr.dtype)), shape=Y.shape)
+    return Y, kw

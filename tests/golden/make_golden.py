@@ -543,7 +543,52 @@ def gen_fw():
     save("fw", **out)
 
 
+# ---------------------------------------------------------------------------
+# H. coverage BCA (block_coordinate.py:600-701), CSR only: the dense branch calls np.product,
+#    which numpy 2 no longer has
+# ---------------------------------------------------------------------------
+
+COVERAGE_CASES = [
+    ("top_f32", "f32", 3, dict(seed=2024)),
+    ("top_f64", "f64", 3, dict(seed=7, max_iters=6)),
+    ("mixed_alpha_f64", "f64", 4, dict(seed=3, alpha=0.5, max_iters=6)),
+    ("mixed_alpha_f32", "f32", 3, dict(seed=3, alpha=0.7, max_iters=6)),
+    ("greedy_f64", "f64", 3, dict(seed=11, init_y_pred="greedy", max_iters=5)),
+    ("no_shuffle_f32", "f32", 5, dict(seed=5, shuffle_order=False, max_iters=4, tolerance=-1.0)),
+    ("explicit_init_f64", "f64", 3, dict(seed=9, max_iters=5)),
+]
+
+
+def gen_coverage():
+    rng = np.random.default_rng(801)
+    n, m, r = 900, 1500, 14
+    out, specs = {}, []
+    mats = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        Y = fixed_csr(rng, n, m, r, dt, zipf=True, skew=True)
+        mats[tag] = Y
+        out.update(csr_fields(f"y_{tag}", Y))
+    for ci, (name, tag, k, kw) in enumerate(COVERAGE_CASES):
+        Y = mats[tag]
+        kw = dict(kw)
+        if name.startswith("explicit_init"):
+            init = predict_weighted_per_instance(Y, k, a=rng.random(m))
+            out[f"c{ci}_init_indices"] = init.indices.copy()
+            kw["init_y_pred"] = init
+        P, meta = ref_bc.predict_optimizing_coverage_using_bc(Y, k, return_meta=True, **kw)
+        assert (np.diff(P.indptr) == k).all()
+        out[f"c{ci}_pred_indices"] = P.indices[: n * k].copy()
+        out[f"c{ci}_utilities"] = np.asarray(meta["utilities"], dtype=np.float64)
+        out[f"c{ci}_iters"] = np.int64(meta["iters"])
+        specs.append(json.dumps(dict(name=name, dtype=tag, k=k,
+                                     kwargs={a: b for a, b in kw.items() if a != "init_y_pred" or isinstance(b, str)},
+                                     explicit_init=name.startswith("explicit_init")), sort_keys=True))
+        print(f"  coverage case {ci} {name}: iters {meta['iters']}, utilities {meta['utilities'][:3]} ...")
+    out["specs"] = np.asarray(specs)
+    save("coverage", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw"]
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage"]
     for w in which:
         globals()["gen_" + w]()

@@ -145,3 +145,21 @@ def test_frank_wolfe_golden():
         pc.sort_indices()
         np.testing.assert_array_equal(pc.indptr, z[f"c{ci}_pred_indptr"], err_msg=name)
         np.testing.assert_array_equal(pc.indices, z[f"c{ci}_pred_indices"], err_msg=name)
+
+
+def test_coverage_bca_golden():
+    """oracle/coverage_ref.py against the reference's predict_optimizing_coverage_using_bc (CSR): identical
+    predictions and iteration counts; utilities to 1e-12 (float64) -- for float32 inputs the reference sums
+    the precision@k part of a mixed utility in float32, the oracle in float64 then rounds: 1e-6."""
+    from oracle import coverage_ref as cov
+
+    z = G.load("coverage")
+    for ci, spec in enumerate(G.coverage_cases(z)):
+        Y, kw = G.coverage_inputs(z, ci, spec)
+        P, meta = cov.predict_optimizing_coverage_using_bc(Y, spec["k"], **kw)
+        name = spec["name"]
+        assert meta["iters"] == int(z[f"c{ci}_iters"]), name
+        tol = 1e-6 if (spec["dtype"] == "f32" and kw.get("alpha", 1) < 1) else 1e-12
+        np.testing.assert_allclose(meta["utilities"], z[f"c{ci}_utilities"], rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_array_equal(P.indices, z[f"c{ci}_pred_indices"], err_msg=name)
+        assert P.dtype == Y.dtype and (np.diff(P.indptr) == spec["k"]).all()
