@@ -458,6 +458,30 @@ int xc_threshold_fill_csr_rowwise(int64_t n, const int32_t *indptr, const int32_
                                   const void *b, int64_t ld, const int32_t *row_classifier,
                                   const int32_t *out_indptr, int32_t *out_indices, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Block coordinate ascent for coverage (block_coordinate.py:600-701).
+ * ef: float64[m], Ef_j = prod_i (1 - pred_ij * eta_ij), the probability that no row
+ * covers label j; utility = 1 - mean(Ef) (mixed with precision@k when alpha < 1).
+ * ------------------------------------------------------------------------- */
+
+/* One sweep of _bc_for_coverage_step_csr (:539-582) over `order`: per row divide its own
+ * factors out of Ef, gain = Ef * eta (alpha * gain + (1 - alpha) * eta / k when alpha < 1),
+ * keep the k largest (ties: lower column), multiply the new factors in.  pred_indices /
+ * pred_eta / sel as in xc_bca_sweep_csr (rows hold >= k entries).  n_waves = 1 is the
+ * reference's sequence bit for bit; more wavefronts update Ef with compare-and-swap
+ * multiplies for the labels that enter or leave a prediction.  greedy: the first sweep of
+ * init_y_pred="greedy" (Ef starts from ones, nothing is divided out). */
+int xc_coverage_sweep_csr(int64_t n_order, const int32_t *order, const int32_t *indptr,
+                          const int32_t *indices, const void *data, int dtype, int max_row_nnz,
+                          int32_t *pred_indices, void *pred_eta, uint8_t *sel, int k, double *ef,
+                          double alpha, int greedy, int n_waves, int64_t *changed, void *stream);
+
+/* Ef from scratch (numba_calculate_prod_csr_mat_mul_ones_minus_mat, numba_csr_functions.py:324-382):
+ * ef must hold ones; every predicted entry multiplies (1 - eta) into its label (eta = 0:
+ * a predicted label the row does not store, no factor). */
+int xc_coverage_product(int64_t n_k, const int32_t *pred_indices, const void *pred_eta, int dtype,
+                        double *ef, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

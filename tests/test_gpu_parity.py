@@ -828,3 +828,58 @@ def test_bca_csr_concurrent_corner_cases(oref, case):
     assert abs(oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n) - mg["utilities"][-1]) < 1e-12
     if case == "rows_of_exactly_k":
         assert np.array_equal(Pg.indices, Y.indices)
+
+
+# ---------------------------------------------------------------------------
+# coverage BCA
+# ---------------------------------------------------------------------------
+
+def test_coverage_bca_golden_exact():
+    """predict_optimizing_coverage_using_bc with bca_waves=1 against the reference's own outputs:
+    identical predictions and iteration counts, utilities to 1e-12 (1e-6 where the reference sums the
+    precision@k part in float32)."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_coverage_using_bc
+    z = G.load("coverage")
+    for ci, spec in enumerate(G.coverage_cases(z)):
+        Y, kw = G.coverage_inputs(z, ci, spec)
+        init = kw.get("init_y_pred")
+        P, meta = predict_optimizing_coverage_using_bc(Y, spec["k"], return_meta=True, bca_waves=1, **kw)
+        name = spec["name"]
+        assert meta["iters"] == int(z[f"c{ci}_iters"]), name
+        tol = 1e-6 if (spec["dtype"] == "f32" and kw.get("alpha", 1) < 1) else 1e-12
+        np.testing.assert_allclose(meta["utilities"], z[f"c{ci}_utilities"], rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_array_equal(P.indices, z[f"c{ci}_pred_indices"], err_msg=name)
+        assert isinstance(P, csr_matrix) and P.dtype == Y.dtype and (np.diff(P.indptr) == spec["k"]).all()
+        assert set(meta) == {"utilities", "iters", "time"}
+        if spec["explicit_init"]:
+            assert P is init   # updated in place and returned
+
+
+@pytest.mark.parametrize("alpha", [1, 0.6])
+def test_coverage_bca_vs_oracle(alpha):
+    """Default (sequential, one wavefront) = the oracle to 1e-12 at 20K x 30K; bca_waves = 16 (rows in
+    flight, compare-and-swap multiplies) lands within 1e-4 -- the coverage landscape has many nearly
+    equivalent optima, so trajectories that differ at all end a few 1e-5 apart."""
+    from oracle import coverage_ref as cov
+    from xcolumns_amd.block_coordinate import predict_optimizing_coverage_using_bc
+    from xcolumns_amd.synthetic import make_csr
+    n, m, k = 20000, 30000, 3
+    Y = make_csr(n, m, 20, seed=31, k=k, zipf=True)
+    Po, mo = cov.predict_optimizing_coverage_using_bc(Y, k, alpha=alpha, seed=4, max_iters=5, tolerance=-1.0)
+    Pe, me = predict_optimizing_coverage_using_bc(Y, k, alpha=alpha, seed=4, max_iters=5, tolerance=-1.0, return_meta=True)
+    tol = 1e-12 if alpha == 1 else 1e-6   # float32 scores: the precision@k part is summed in float64 here
+    np.testing.assert_allclose(me["utilities"], mo["utilities"], rtol=0, atol=tol)
+    np.testing.assert_array_equal(Pe.indices, Po.indices)
+    Pg, mg = predict_optimizing_coverage_using_bc(Y, k, alpha=alpha, seed=4, max_iters=5, tolerance=-1.0, return_meta=True,
+                                                  bca_waves=16)
+    diff = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print("coverage, 16 wavefronts vs sequential, utility diff per sweep:", diff)
+    assert mg["iters"] == mo["iters"] == 5 and diff.max() < 1e-4, (mg["utilities"], mo["utilities"])
+    assert (np.diff(Pg.indptr) == k).all() and Pg.dtype == Y.dtype
+    # the reported utility is the utility of the returned prediction
+    Ef = cov.failure_probabilities(Y, Pg.indices, k)
+    assert abs(cov.coverage_utility(Y, Pg.indices, Ef, k, alpha) - mg["utilities"][-1]) < 1e-6
+    with pytest.raises(NotImplementedError):
+        predict_optimizing_coverage_using_bc(Y[:10].toarray(), k)
+    with pytest.raises(ValueError):
+        predict_optimizing_coverage_using_bc(Y, 0)

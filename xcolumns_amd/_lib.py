@@ -73,6 +73,9 @@ SIGNATURES = {
     "xc_event_synchronize": (c_int, [c_void_p]),
     "xc_host_alloc_pinned": (c_int, [POINTER(c_void_p), c_int64]),
     "xc_host_free_pinned": (c_int, [c_void_p]),
+    "xc_coverage_sweep_csr": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_void_p, c_double, c_int, c_int, c_void_p, c_void_p]),
+    "xc_coverage_product": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_fw_gradient": (c_int, [c_int64, c_void_p, POINTER(XcMetric), c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "xc_fw_alpha_chunks": (c_int, [c_int64]),
     "xc_fw_alpha_curve": (c_int, [c_int64, c_void_p, c_void_p, POINTER(XcMetric), c_int, c_void_p, c_void_p, c_void_p]),
