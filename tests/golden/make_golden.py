@@ -588,7 +588,61 @@ def gen_coverage():
     save("coverage", **out)
 
 
+# ---------------------------------------------------------------------------
+# I. on-disk inputs of the experiment drivers (experiments/utils.py:113-228)
+# ---------------------------------------------------------------------------
+
+def gen_io():
+    import importlib.util
+    import tempfile
+
+    spec = importlib.util.spec_from_file_location("ref_experiments_utils", os.path.join(REFERENCE, "experiments", "utils.py"))
+    ref_io = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_io)
+    rng = np.random.default_rng(901)
+    n, m = 60, 40
+    # XMC-repository style label file: header, "l1,l2 f:v f:v", rows without labels, one unsorted row
+    lines = [f"{n} 25 {m}"]
+    for i in range(n):
+        r = int(rng.integers(0, 5))
+        labs = rng.choice(m, r, replace=False)
+        if i % 7 != 3:
+            labs = np.sort(labs)
+        feats = " ".join(f"{int(f)}:{rng.random():.4f}" for f in np.sort(rng.choice(25, 3, replace=False)))
+        lines.append(",".join(str(int(x)) for x in labs) + " " + feats)
+    labels_txt = "\n".join(lines) + "\n"
+    # libsvm-like prediction files: one with sorted rows, one with rows in score order
+    def pred_text(sort_rows):
+        out = []
+        for i in range(n):
+            r = int(rng.integers(0, 6))
+            cols = rng.choice(m, r, replace=False)
+            vals = rng.random(r)
+            order = np.argsort(cols) if sort_rows else np.argsort(-vals)
+            out.append(" ".join(f"{int(cols[j])}:{vals[j]:.6f}" for j in order))
+        return "\n".join(out) + "\n"
+    pred_sorted_txt, pred_unsorted_txt = pred_text(True), pred_text(False)
+    npy_labels = np.stack([rng.choice(m, 4, replace=False) for _ in range(n)]).astype(np.int64)
+    npy_scores = rng.random((n, 4)).astype(np.float32)
+    out = {"labels_txt": np.asarray(labels_txt), "pred_sorted_txt": np.asarray(pred_sorted_txt),
+           "pred_unsorted_txt": np.asarray(pred_unsorted_txt), "npy_labels": npy_labels, "npy_scores": npy_scores}
+    with tempfile.TemporaryDirectory() as d:
+        def write(name, text):
+            path = os.path.join(d, name)
+            with open(path, "w") as f:
+                f.write(text)
+            return path
+        out.update(csr_fields("labels", ref_io.load_txt_labels(write("labels.txt", labels_txt))))
+        out.update(csr_fields("pred_sorted", ref_io.load_txt_sparse_pred(write("ps.txt", pred_sorted_txt))))
+        out.update(csr_fields("pred_unsorted", ref_io.load_txt_sparse_pred(write("pu.txt", pred_unsorted_txt))))
+        base = os.path.join(d, "top")
+        np.save(base + "-labels.npy", npy_labels)
+        np.save(base + "-scores.npy", npy_scores)
+        out.update(csr_fields("npy_pair", ref_io.load_npy_sparse_pred(base)))
+    save("io", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage"]
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage", "io"]
     for w in which:
         globals()["gen_" + w]()

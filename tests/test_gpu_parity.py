@@ -883,3 +883,22 @@ def test_coverage_bca_vs_oracle(alpha):
         predict_optimizing_coverage_using_bc(Y[:10].toarray(), k)
     with pytest.raises(ValueError):
         predict_optimizing_coverage_using_bc(Y, 0)
+
+
+def test_io_dense_scores_to_topk_csr_and_device(tmp_path):
+    """load_npy_full_pred (experiments/utils.py:198-210): the k largest scores of every row of a dense .npy
+    matrix as a CSR matrix with sorted column ids -- selected on the GPU -- and its upload for the kernels."""
+    from xcolumns_amd import io as xio
+    rng = np.random.default_rng(12)
+    dense = rng.random((300, 500)).astype(np.float32)
+    path = str(tmp_path / "scores.npy")
+    np.save(path, dense)
+    k = 7
+    mat = xio.load_npy_full_pred(path, keep_top_k=k)
+    assert mat.shape == (300, 500) and mat.dtype == np.float32 and (np.diff(mat.indptr) == k).all()
+    top = np.sort(np.argsort(-dense, axis=1)[:, :k], axis=1)
+    assert np.array_equal(mat.indices.reshape(300, k), top)
+    assert np.array_equal(mat.data.reshape(300, k), np.take_along_axis(dense, top, axis=1))
+    assert xio.load_npy_full_pred(path).nnz == 0   # keep_top_k = 0, as in the reference
+    d = xio.to_device(mat)
+    assert d.indices.is_cuda and d.indices.dtype == torch.int32 and d.max_row_nnz == k
