@@ -899,6 +899,6 @@ def test_io_dense_scores_to_topk_csr_and_device(tmp_path):
     top = np.sort(np.argsort(-dense, axis=1)[:, :k], axis=1)
     assert np.array_equal(mat.indices.reshape(300, k), top)
     assert np.array_equal(mat.data.reshape(300, k), np.take_along_axis(dense, top, axis=1))
-    assert xio.load_npy_full_pred(path).nnz == 0   # keep_top_k = 0, as in the reference
+    assert xio.load_npy_full_pred(path).nnz == 0   # keep_top_k = 0: nothing kept
     d = xio.to_device(mat)
     assert d.indices.is_cuda and d.indices.dtype == torch.int32 and d.max_row_nnz == k

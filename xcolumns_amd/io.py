@@ -94,8 +94,10 @@ def load_npy_full_pred(path: str, keep_top_k: int = 0, **kwargs) -> csr_matrix:
         raise ValueError("keep_top_k must be >= 0 (the reference's negative branch reads an undefined variable)")
     n = dense.shape[0]
     if keep_top_k == 0:
+        # (the reference's default fails here: scipy cannot infer the shape of an empty matrix)
         return construct_csr_matrix(np.zeros(0, dtype=dense.dtype), np.zeros(0, dtype=np.int64),
-                                    np.zeros(n + 1, dtype=np.int32), dtype=np.float32, sort_indices=True)
+                                    np.zeros(n + 1, dtype=np.int32), dtype=np.float32, shape=dense.shape,
+                                    sort_indices=True)
     dev = D.require_gpu()
     vals, idx = torch.topk(torch.from_numpy(np.ascontiguousarray(dense)).to(dev), keep_top_k, dim=1)
     indptr = np.arange(0, n + 1, 1, dtype=np.int32) * keep_top_k
