@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): many small random problems through the exact modes of the product
+against the CPU oracle -- BCA (CSR and dense), weighted top-k, confusion matrix, coverage.  Anything
+that is not bit-identical (indices) / within 1e-12 (utilities) is printed with its seed.
+
+    python tests/studies/fuzz_exact.py [cases] [first_seed]
+"""
+import os
+import sys
+import traceback
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import coverage_ref as ocov  # noqa: E402  (checker)
+from oracle import ref as oref  # noqa: E402
+import xcolumns_amd.block_coordinate as bc  # noqa: E402
+from xcolumns_amd.confusion_matrix import calculate_confusion_matrix  # noqa: E402
+from xcolumns_amd.weighted_prediction import predict_weighted_per_instance  # noqa: E402
+
+METRICS = [("binary_precision_on_conf_matrix", oref.PRECISION), ("binary_recall_on_conf_matrix", oref.RECALL),
+           ("binary_f1_score_on_conf_matrix", oref.FBETA), ("binary_jaccard_score_on_conf_matrix", oref.JACCARD),
+           ("binary_balanced_accuracy_on_conf_matrix", oref.BALANCED_ACC), ("binary_gmean_on_conf_matrix", oref.GMEAN),
+           ("binary_hmean_on_conf_matrix", oref.HMEAN)]
+
+
+def problem(rng):
+    n = int(rng.integers(1, 400))
+    m = int(rng.integers(2, 300))
+    k = int(rng.integers(1, min(m, 12) + 1))
+    rmax = int(rng.integers(k, min(m, 70) + 1))
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    lens = rng.integers(k, rmax + 1, size=n)
+    cols = np.concatenate([np.sort(rng.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
+    grid = rng.random() < 0.3   # ties
+    vals = (rng.integers(1, 9, size=cols.size) / 8.0) if grid else rng.random(cols.size) ** rng.integers(1, 4)
+    Y = csr_matrix((vals.astype(dtype), cols, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)), shape=(n, m))
+    return Y, k
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    Y, k = problem(rng)
+    n, m = Y.shape
+    what = rng.choice(["bca_csr", "bca_csr", "bca_dense", "topk", "confusion", "coverage"])
+    if what.startswith("bca"):
+        name, base = METRICS[int(rng.integers(len(METRICS)))]
+        kw = dict(seed=int(rng.integers(1000)), max_iters=int(rng.integers(1, 5)), tolerance=float(rng.choice([-1.0, 1e-6])),
+                  skip_tn=bool(rng.random() < 0.5), maximize=bool(rng.random() < 0.85),
+                  metric_aggregation=str(rng.choice(["mean", "sum"])), shuffle_order=bool(rng.random() < 0.8),
+                  init_y_pred=str(rng.choice(["top", "random", "greedy"])))
+        if not kw["maximize"]:
+            kw["tolerance"] = abs(kw["tolerance"])
+        metric = oref.make_metric(base, k=float(k), m=float(m))
+        Yin = Y if what == "bca_csr" else Y.toarray()
+        Po, mo = oref.predict_using_bc_with_0approx(Yin, metric, k, **kw)
+        Pg, mg = bc.predict_using_bc_with_0approx(Yin, getattr(bc, name), k, return_meta=True, bca_waves=1, **kw)
+        if np.isnan(mo["utilities"]).any():
+            return True, "skipped: the utility is NaN (a tn-based metric with skip_tn=True): the reference's own selection among NaN gains is arbitrary"
+        ok = mg["iters"] == mo["iters"] and np.allclose(mg["utilities"], mo["utilities"], rtol=1e-13, atol=1e-12)
+        ok = ok and (np.array_equal(Pg.indices, Po.indices) if what == "bca_csr" else np.array_equal(Pg, Po))
+        return ok, f"{what} {name} n={n} m={m} k={k} {Y.dtype} {kw}"
+    if what == "topk":
+        a = rng.normal(size=m) if rng.random() < 0.5 else None
+        b = rng.normal(size=m) if rng.random() < 0.5 else None
+        keep = bool(rng.random() < 0.3)
+        kk = int(rng.integers(0, k + 1))
+        Pg = predict_weighted_per_instance(Y, kk, th=0.3, a=a, b=b, keep_scores=keep)
+        Po = oref.predict_weighted_per_instance(Y, kk, th=0.3, a=a, b=b, keep_scores=keep)
+        ok = np.array_equal(Pg.indptr, Po.indptr) and np.array_equal(Pg.indices, Po.indices) and np.array_equal(Pg.data, Po.data)
+        return ok, f"topk n={n} m={m} k={kk} {Y.dtype} a={a is not None} b={b is not None} keep={keep}"
+    if what == "confusion":
+        T = Y.copy()
+        T.data = (rng.random(T.nnz) < 0.4).astype(Y.dtype) if rng.random() < 0.5 else T.data
+        P = oref.predict_weighted_per_instance(Y, k, a=rng.normal(size=m))
+        got = calculate_confusion_matrix(T, P, normalize=bool(rng.random() < 0.5), skip_tn=False, dtype=np.float64)
+        exp = oref.calculate_confusion_matrix(T, P, normalize=False, skip_tn=False)
+        # compare unnormalised: undo the normalisation
+        scale = n if abs(got.tp.sum() + got.fp.sum() + got.fn.sum() + got.tn.sum() - m) < 1e-6 else 1
+        ok = all(np.allclose(np.asarray(g) * scale, e, rtol=0, atol=1e-9) for g, e in zip(got, exp))
+        return ok, f"confusion n={n} m={m} k={k} {Y.dtype}"
+    alpha = float(rng.choice([1.0, 0.5, 0.8]))
+    kw = dict(alpha=alpha, seed=int(rng.integers(1000)), max_iters=int(rng.integers(1, 5)),
+              init_y_pred=str(rng.choice(["top", "random", "greedy"])), shuffle_order=bool(rng.random() < 0.8))
+    Po, mo = ocov.predict_optimizing_coverage_using_bc(Y, k, **kw)
+    Pg, mg = bc.predict_optimizing_coverage_using_bc(Y, k, return_meta=True, **kw)
+    tol = 1e-12 if (alpha == 1 or Y.dtype == np.float64) else 1e-6
+    ok = mg["iters"] == mo["iters"] and np.allclose(mg["utilities"], mo["utilities"], rtol=0, atol=tol) \
+        and np.array_equal(Pg.indices, Po.indices)
+    return ok, f"coverage n={n} m={m} k={k} {Y.dtype} {kw}"
+
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for seed in range(first, first + cases):
+    try:
+        ok, desc = one(seed)
+    except Exception as e:  # noqa: BLE001
+        ok, desc = False, f"raised {type(e).__name__}: {e}\n{traceback.format_exc(limit=3)}"
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed={seed}: {desc}", flush=True)
+print(f"{cases} cases from seed {first}: {bad} mismatches", flush=True)
