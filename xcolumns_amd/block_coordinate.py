@@ -76,9 +76,12 @@ class WavePolicy:
     """Number of concurrent wavefronts for the next sweep."""
 
     def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None,
-                 world: int = 1, k: int = 5):
+                 world: int = 1, k: int = 5, first_changed: float = 0.5):
         """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows
-        (the changed-row count fed to :meth:`next` is the global one); `k`: labels per row."""
+        (the changed-row count fed to :meth:`next` is the global one); `k`: labels per row;
+        `first_changed`: expected share of rows the first sweep changes (about half from the top-k
+        prediction, all of them from a random or foreign one)."""
+        self.first_changed = float(first_changed)
         self.world = max(1, int(world))
         env = os.environ.get("XCOLUMNS_BCA_WAVES")
         self.fixed = int(fixed) if fixed else (int(env) if env else None)
@@ -97,7 +100,7 @@ class WavePolicy:
             return int(max(1, min(self.cap, self.n, self.budget * self.n / 32)))
         # sharded rows: the other ranks' updates are invisible within a sweep whatever W is (DESIGN.md
         # section 7), but this rank's own rows still follow the budget, on its share of the changes
-        changed = self.n / 2 if changed_prev is None else max(1.0, changed_prev / self.world)
+        changed = self.n * self.first_changed if changed_prev is None else max(1.0, changed_prev / self.world)
         want = int(self.budget * self.n * self.n / changed)
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
 
@@ -604,7 +607,18 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
         eng.init_indices(torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)))
 
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
-    policy = WavePolicy(n_u, fixed=bca_waves, k=k)
+    if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
+        # Macro precision tp / (tp + fp) jumps when a rarely predicted label gains or loses a row: rows in
+        # flight that pick the same attractive label all take it, and the run ends 1e-4 .. 1e-3 BELOW the
+        # sequential one even with two wavefronts (tests/studies/fuzz_concurrent.py).  Parity first: the
+        # reference's sequential sweep unless the caller sets bca_waves.
+        log_info("  macro precision: using the sequential sweep (bca_waves=1); set bca_waves to trade parity for speed",
+                 verbose)
+        bca_waves = 1
+    # a random / foreign / greedy start changes every row in sweep 1 and keeps many rows moving for several
+    # sweeps (measured 5e-5 .. 1.2e-4 at the top-k width): half the budget for the whole run
+    policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if init_idx is None else 1.0,
+                        budget=None if init_idx is None else _STALE_BUDGET / 2)
     run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                    policy, verbose, meta)
 
