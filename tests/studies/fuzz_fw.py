@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of Frank-Wolfe (GPU box): small random problems through
+find_classifier_using_fw + RandomizedWeightedClassifier.predict against oracle/fw_ref.py: same iteration
+count, step sizes, classifier probabilities and predicted label sets; utilities to 1e-12 for float64 inputs
+(float32 inputs: the reference's float32 first evaluations, 2e-6).
+
+    python tests/studies/fuzz_fw.py [cases] [first_seed]
+"""
+import os
+import sys
+import traceback
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import fw_ref as fw  # noqa: E402  (checker)
+import xcolumns_amd.frank_wolfe as xfw  # noqa: E402
+import xcolumns_amd.metrics as xm  # noqa: E402
+
+STEMS = {"precision": fw.PRECISION, "recall": fw.RECALL, "f1_score": fw.FBETA, "jaccard_score": fw.JACCARD,
+         "balanced_accuracy": fw.BALANCED_ACC, "hmean": fw.HMEAN}
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    n, m = int(rng.integers(50, 1500)), int(rng.integers(5, 200))
+    k = int(rng.integers(0, min(m, 6) + 1))
+    dtype = np.float64 if rng.random() < 0.6 else np.float32
+    dense = rng.random() < 0.3
+    rmax = int(rng.integers(max(k, 1), min(m, 40) + 1))
+    lens = rng.integers(0 if rng.random() < 0.3 else max(k, 1), rmax + 1, size=n)
+    cols = np.concatenate([np.sort(rng.choice(m, l, replace=False)) for l in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    w = 0.05 + 0.95 * rng.random(m) ** 2
+    eta = ((rng.random(cols.size) ** 2) * w[cols]).astype(dtype)
+    Yp = csr_matrix((eta, cols, indptr), shape=(n, m))
+    Yt = csr_matrix(((rng.random(cols.size) < eta).astype(dtype), cols.copy(), indptr.copy()), shape=(n, m))
+    Yt.eliminate_zeros()
+    stem = str(rng.choice(list(STEMS)))
+    avg = str(rng.choice(["macro", "micro"]))
+    skip_tn = stem not in ("balanced_accuracy", "hmean")
+    kw = dict(max_iters=int(rng.integers(1, 6)), init_classifier=str(rng.choice(["top", "random", "prior"])),
+              seed=int(rng.integers(1000)), skip_tn=skip_tn,
+              alpha_search_algo=str(rng.choice(["uniform", "uniform", "ternary"])),
+              search_for_best_alpha=bool(rng.random() < 0.85), alpha_uniform_search_step=float(rng.choice([0.01, 0.001])),
+              normalize_conf_matrix=bool(rng.random() < 0.85))
+    yt, yp = (Yt.toarray(), Yp.toarray()) if dense else (Yt, Yp)
+    A, B, P, mo = fw.find_classifier_using_fw(yt, yp, fw.FwMetric(base=STEMS[stem], average=avg), k, **kw)
+    clf, mg = xfw.find_classifier_using_fw(yt, yp, getattr(xm, f"{avg}_{stem}_on_conf_matrix"), k, return_meta=True, **kw)
+    desc = f"n={n} m={m} k={k} {np.dtype(dtype).name} dense={dense} {avg}_{stem} {kw}"
+    if not np.isfinite(A).all() or not np.isfinite(mo["utilities"]).all():
+        return True, "skipped (non-finite classifier or utility in the oracle too)"
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    ok = mg["iters"] == mo["iters"] and np.array_equal(np.asarray(mg["alphas"], dtype=np.float64), np.asarray(mo["alphas"], dtype=np.float64))
+    ok = ok and np.allclose(mg["utilities"], mo["utilities"], rtol=tol, atol=tol) and np.array_equal(clf.p, P)
+    scale = float(np.abs(A).max()) or 1.0
+    ok = ok and np.allclose(clf.a, A, rtol=5e-6, atol=5e-7 * scale) and np.allclose(clf.b, B, rtol=5e-6, atol=5e-7 * scale)
+    pg = clf.predict(yp, seed=3)
+    po = fw.predict_using_randomized_weighted_classifier(yp, k, clf.a, clf.b, clf.p, seed=3)
+    if dense:
+        ok = ok and np.array_equal(pg, po)
+    else:
+        ok = ok and np.array_equal(pg.indptr, po.indptr) and np.array_equal(pg.indices, po.indices)
+    return ok, desc
+
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for seed in range(first, first + cases):
+    try:
+        ok, desc = one(seed)
+    except Exception as e:  # noqa: BLE001
+        ok, desc = False, f"raised {type(e).__name__}: {e}\n{traceback.format_exc(limit=4)}"
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed={seed}: {desc}", flush=True)
+print(f"{cases} cases from seed {first}: {bad} mismatches", flush=True)
