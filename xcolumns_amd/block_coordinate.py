@@ -695,7 +695,11 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
     # rows in flight: the CSR policy (one workgroup here = one "wavefront" there), bounded by the
     # workgroups the GPU holds; bca_waves=1 is the reference's sequential sweep
-    policy = WavePolicy(n_u, fixed=bca_waves, k=max(1, k))
+    if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
+        bca_waves = 1   # macro precision is chaotic under any concurrency (see _bc_csr): sequential by default
+    policy = WavePolicy(n_u, fixed=bca_waves, k=max(1, k),
+                        first_changed=0.5 if (isinstance(init_y_pred, str) and init_y_pred == "top") else 1.0,
+                        budget=None if (isinstance(init_y_pred, str) and init_y_pred == "top") else _STALE_BUDGET / 2)
     max_blocks = max(1, policy.cap // _DENSE_BLOCK_WAVES)
     changed = torch.zeros(1, dtype=torch.int64, device=dev)
     changed_prev = None
