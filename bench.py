@@ -156,6 +156,8 @@ def main():
         rule and the wavefront policy are evaluated on the GPU at every boundary, the host enqueues
         sweep j + 1 before it reads the result of sweep j (one D2H of 4 doubles per boundary)."""
         out = []
+        if first >= last:
+            return out
         if not pipelined:   # bca_waves = 1 (--waves 1): the host-paced exact loop
             changed = None
             for s in range(first, last):
