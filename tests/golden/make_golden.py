@@ -420,6 +420,27 @@ def gen_eval():
         assert abs(out["csr_" + name] - out["dense_" + name]) < 1e-12, name
     out["names"] = np.asarray(EVAL_NAMES)
     out["label_priors"] = np.asarray(ref_metrics.label_priors(Ld))
+    # the rest of the evaluation set (metrics.py:17-35, :175-281, :331-397, :422-583, :972-1003)
+    priors = np.asarray(ref_metrics.label_priors(Ld)).ravel()
+    inv_ps = np.asarray(ref_metrics.jpv_inverse_propensities(Ld)).ravel()   # (the reference's own fails on CSR: matrix ** -a)
+    out["x_priors"], out["x_k"] = priors, np.int64(k)
+    out["x_jpv_inverse_propensities"] = inv_ps
+    out["x_jpv_propensities"] = np.asarray(ref_metrics.jpv_propensities(Ld, a=0.6, b=2.6)).ravel()
+    extra = {
+        "binary_accuracy": {}, "binary_0_1_loss": {}, "hamming_score": {}, "hamming_loss": {},
+        "precision_at_k": dict(k=k), "weighted_precision_at_k": dict(k=k, w=inv_ps), "coverage": {},
+        "abandonment": {}, "tail_abandonment": dict(priors=priors), "tail_recall": dict(priors=priors, percentile=0.3),
+    }
+    for name, kw in extra.items():
+        f = getattr(ref_metrics, name)
+        out["xcsr_" + name] = np.asarray(f(L, P, **kw), dtype=np.float64)
+        out["xdense_" + name] = np.asarray(f(Ld, Pd, **kw), dtype=np.float64)
+    out["xcsr_instance_tail_recall_at_k"] = np.float64(ref_metrics.instance_tail_recall_at_k(L, P, k, priors, percentile=0.4))
+    out["xcsr_instance_tail_metric"] = np.float64(ref_metrics.instance_tail_metric(
+        L, P, ref_metrics.binary_precision_on_conf_matrix, k, priors, percentile=0.6))
+    out["x_check_at_k"] = np.asarray([ref_metrics.check_if_y_pred_at_k(P, k), ref_metrics.check_if_y_pred_at_k(P, k + 1),
+                                      ref_metrics.check_if_y_pred_at_k(Pd, k), ref_metrics.check_if_y_pred_at_k(L, k)])
+    out["extra_names"] = np.asarray(list(extra))
     save("eval_f64", **out)
 
 

@@ -618,6 +618,26 @@ def test_evaluation_metrics_golden():
         assert abs(f(L, P) - float(z["csr_" + name])) < 1e-12, name
         assert abs(f(z["ld"], z["pd"]) - float(z["dense_" + name])) < 1e-12, name
     assert np.allclose(pm.label_priors(z["ld"]), z["label_priors"], rtol=0, atol=1e-15)
+    # the rest of the evaluation set: accuracy / Hamming, precision@k (plain and propensity-weighted),
+    # coverage / abandonment, tail variants, the propensity model, the at-k check
+    k, priors, inv_ps = int(z["x_k"]), z["x_priors"], z["x_jpv_inverse_propensities"]
+    kwargs = {"precision_at_k": dict(k=k), "weighted_precision_at_k": dict(k=k, w=inv_ps),
+              "tail_abandonment": dict(priors=priors), "tail_recall": dict(priors=priors, percentile=0.3)}
+    for name in [str(s) for s in z["extra_names"]]:
+        f = getattr(pm, name)
+        kw = kwargs.get(name, {})
+        np.testing.assert_allclose(np.asarray(f(L, P, **kw), dtype=np.float64), z["xcsr_" + name], rtol=0, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(np.asarray(f(z["ld"], z["pd"], **kw), dtype=np.float64), z["xdense_" + name], rtol=0,
+                                   atol=1e-12, err_msg=name)
+    assert abs(pm.instance_tail_recall_at_k(L, P, k, priors, percentile=0.4) - float(z["xcsr_instance_tail_recall_at_k"])) < 1e-12
+    assert abs(pm.instance_tail_metric(L, P, pm.binary_precision_on_conf_matrix, k, priors, percentile=0.6)
+               - float(z["xcsr_instance_tail_metric"])) < 1e-12
+    np.testing.assert_allclose(np.asarray(pm.jpv_inverse_propensities(z["ld"])).ravel(), inv_ps, rtol=1e-15)
+    np.testing.assert_allclose(np.asarray(pm.jpv_inverse_propensities(L)).ravel(), inv_ps, rtol=1e-15)
+    np.testing.assert_allclose(np.asarray(pm.jpv_propensities(z["ld"], a=0.6, b=2.6)).ravel(), z["x_jpv_propensities"], rtol=1e-15)
+    got = [pm.check_if_y_pred_at_k(P, k), pm.check_if_y_pred_at_k(P, k + 1), pm.check_if_y_pred_at_k(z["pd"], k),
+           pm.check_if_y_pred_at_k(L, k)]
+    assert got == [bool(x) for x in z["x_check_at_k"]]
 
 
 # ---------------------------------------------------------------------------

@@ -18,6 +18,8 @@ from typing import Any, Callable, Dict, Optional
 
 import numpy as np
 
+import torch
+
 from . import _lib
 
 
@@ -349,3 +351,144 @@ def label_priors(y):
 
 def inverse_label_priors(y):
     return 1.0 / label_priors(y)
+
+
+# ---------------------------------------------------------------------------
+# the rest of the reference's evaluation set (metrics.py:17-35, :175-281, :331-397, :422-493,
+# :516-583, :972-1003): accuracy / Hamming, precision@k and its propensity-weighted form,
+# coverage / abandonment, the tail variants and the Jain et al. propensity model.  All of it is
+# O(m) or O(n) arithmetic on the statistics the fused GPU pass returns.
+# ---------------------------------------------------------------------------
+
+def check_if_y_pred_at_k(y_pred, k: int) -> bool:
+    """True if every row of `y_pred` sums to k > 0 (metrics.py:17-35; its "binary matrix" check
+    tests ``(y == 0) & (y == 1)``, which never holds, and is kept as it is)."""
+    from scipy.sparse import csr_matrix
+
+    values = y_pred.data if isinstance(y_pred, csr_matrix) else y_pred
+    if ((values == 0) & (values == 1)).any():
+        raise ValueError("y_pred must be a binary matrix")
+    return k > 0 and bool((y_pred.sum(axis=1) == k).all())
+
+
+def binary_0_1_loss_on_conf_matrix(tp, fp, fn, tn, normalize: bool = True):
+    """(fp + fn) / (tp + fp + fn + tn), or fp + fn when not normalised (metrics.py:422-441)."""
+    loss = fp + fn
+    if normalize:
+        loss /= tp + fp + fn + tn
+    return loss
+
+
+def hamming_score_on_conf_matrix(tp, fp, fn, tn, normalize: bool = True):
+    """Mean over labels of the binary accuracy (metrics.py:444-458)."""
+    return binary_accuracy_on_conf_matrix(tp, fp, fn, tn, normalize=normalize).mean()
+
+
+def hamming_loss_on_conf_matrix(tp, fp, fn, tn, normalize: bool = True):
+    """Mean over labels of the binary 0/1 loss (metrics.py:461-475)."""
+    return binary_0_1_loss_on_conf_matrix(tp, fp, fn, tn, normalize=normalize).mean()
+
+
+def precision_at_k_on_conf_matrix(tp, fp, fn, tn, k: int):
+    """Sum over labels of tp / k (metrics.py:516-527)."""
+    return binary_precision_at_k_on_conf_matrix(tp, fp, fn, tn, k).sum()
+
+
+def binary_weighted_precision_at_k_on_conf_matrix(tp, fp, fn, tn, k: int, w):
+    """w * tp / k per label (metrics.py:540-557); w: e.g. inverse propensities."""
+    return w * tp / k
+
+
+def weighted_precision_at_k_on_conf_matrix(tp, fp, fn, tn, k: int, w):
+    """Sum over labels of w * tp / k (metrics.py:560-572)."""
+    return binary_weighted_precision_at_k_on_conf_matrix(tp, fp, fn, tn, k, w).sum()
+
+
+def coverage_on_conf_matrix(tp, fp, fn, tn):
+    """Share of labels (or, per row, of instances) with at least one true positive (metrics.py:972-990)."""
+    return (tp > 0).mean()
+
+
+def make_tail_instance_metric_on_y_true_and_y_pred(binary_metric: Callable, metric_name: str,
+                                                   skip_tn: bool = False) -> Callable:
+    """Instance-averaged metric restricted to tail labels: labels whose prior is above the given
+    percentile are removed from y_true first (metrics.py:175-225)."""
+
+    def tail_instance_metric_on_y_true_and_y_pred(y_true, y_pred, priors, percentile: float = 0.5, **kwargs):
+        import numpy as np
+        from scipy.sparse import issparse
+
+        from .confusion_matrix import calculate_confusion_matrix
+
+        w = np.array(priors, copy=True)
+        p = np.percentile(w, percentile * 100)
+        w[w <= p] = 1.0
+        w[w > p] = 0.0
+        y_tail = y_true.multiply(w).tocsr() if issparse(y_true) else y_true * w
+        C = calculate_confusion_matrix(y_tail, y_pred, normalize=False, skip_tn=skip_tn, axis=1)
+        return binary_metric(*C, **kwargs).mean()
+
+    tail_instance_metric_on_y_true_and_y_pred.__doc__ = (
+        f"Tail instance-averaged {metric_name}: {binary_metric.__name__} per row on the labels at or below the "
+        "prior percentile.")
+    return _with_kwargs_of(tail_instance_metric_on_y_true_and_y_pred, binary_metric)
+
+
+def _tail_mask(w, percentile: float):
+    import numpy as np
+
+    w = np.array(w, copy=True)
+    p = np.percentile(w, percentile * 100)
+    w[w < p] = 0.0
+    w[w >= p] = 1.0
+    return w
+
+
+def instance_tail_metric(y_true, y_pred, metric_on_conf_matrix_func: Callable, k: int, w, percentile: float = 0.5,
+                         epsilon: float = 1e-9):
+    """metrics.py:232-252: `metric_on_conf_matrix_func` per row on the labels whose weight is at or above
+    the percentile (note the opposite side to the tail_* factories), averaged over rows."""
+    from .confusion_matrix import calculate_confusion_matrix
+
+    y_tail = y_true.multiply(_tail_mask(w, percentile)).tocsr()
+    C = calculate_confusion_matrix(y_tail, y_pred, normalize=False, skip_tn=True, axis=1)
+    return metric_on_conf_matrix_func(*C, epsilon=epsilon).mean()
+
+
+def instance_tail_recall_at_k(y_true, y_pred, k: int, w, percentile: float = 0.5, epsilon: float = 1e-9):
+    """metrics.py:255-281: :func:`instance_tail_metric` with the binary recall."""
+    return instance_tail_metric(y_true, y_pred, binary_recall_on_conf_matrix, k, w, percentile=percentile,
+                                epsilon=epsilon)
+
+
+def jpv_inverse_propensities(y, a: float = 0.55, b: float = 1.5):
+    """Inverse label propensities of Jain et al. 2016: 1 + C (n_j + b)^-a, C = (log n - 1)(b + 1)^a
+    (metrics.py:361-397)."""
+    from math import log
+
+    import numpy as np
+
+    n = y.shape[0]
+    C = (log(n) - 1) * (b + 1) ** a
+    counts = label_counts(y)
+    if not isinstance(counts, torch.Tensor):
+        counts = np.asarray(counts).ravel()   # scipy gives a 1 x m matrix, on which ** would be a matrix power
+    return 1 + C * (counts + b) ** -a
+
+
+def jpv_propensities(y, a: float = 0.55, b: float = 1.5):
+    """1 / :func:`jpv_inverse_propensities` (metrics.py:331-358)."""
+    return 1.0 / jpv_inverse_propensities(y, a, b)
+
+
+binary_accuracy = make_metric_on_y_true_and_y_pred(binary_accuracy_on_conf_matrix, "accuracy")
+binary_0_1_loss = make_metric_on_y_true_and_y_pred(binary_0_1_loss_on_conf_matrix, "0/1 loss")
+hamming_score = make_metric_on_y_true_and_y_pred(hamming_score_on_conf_matrix, "Hamming score")
+hamming_loss = make_metric_on_y_true_and_y_pred(hamming_loss_on_conf_matrix, "Hamming loss")
+precision_at_k = make_metric_on_y_true_and_y_pred(precision_at_k_on_conf_matrix, "precision at k", skip_tn=True)
+weighted_precision_at_k = make_metric_on_y_true_and_y_pred(weighted_precision_at_k_on_conf_matrix,
+                                                           "weighted precision at k", skip_tn=True)
+coverage = make_metric_on_y_true_and_y_pred(coverage_on_conf_matrix, "coverage", skip_tn=True)
+abandonment = make_instance_metric_on_y_true_and_y_pred(coverage_on_conf_matrix, "abandonment", skip_tn=True)
+tail_abandonment = make_tail_instance_metric_on_y_true_and_y_pred(coverage_on_conf_matrix, "tail abandonment", skip_tn=True)
+tail_recall = make_tail_instance_metric_on_y_true_and_y_pred(binary_recall_on_conf_matrix, "recall", skip_tn=True)

@@ -54,6 +54,11 @@ def ones_like(a, shape: Tuple[int, ...] = None, dtype=None):
     return _filled_like(a, 1, shape, dtype)
 
 
+def random_at_k_like(a, shape: Tuple[int, int], k: int, seed: Optional[int] = None):
+    """Declared but empty in the reference (utils.py:97-100); kept so imports keep working."""
+    return None
+
+
 def random_at_k_np(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[int] = None) -> np.ndarray:
     """k random labels per row, the numpy Generator stream of utils.py:103-116
     (``rng.choice(m, k, replace=False, shuffle=False)`` row by row)."""
