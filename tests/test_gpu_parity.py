@@ -922,3 +922,34 @@ def test_io_dense_scores_to_topk_csr_and_device(tmp_path):
     assert xio.load_npy_full_pred(path).nnz == 0   # keep_top_k = 0: nothing kept
     d = xio.to_device(mat)
     assert d.indices.is_cuda and d.indices.dtype == torch.int32 and d.max_row_nnz == k
+
+
+def test_block_coordinate_reference_test_properties():
+    """The reference's own BCA test (tests/test_block_coordinate.py:33-96), on synthetic data: for every
+    input type the prediction keeps type / dtype / k labels per row; BCA for macro recall scores at least
+    as well as top-k on the true labels and lands within 0.02 of the closed-form optimum
+    (predict_optimizing_macro_recall with the label priors)."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_recall_using_bc
+    from xcolumns_amd.confusion_matrix import calculate_confusion_matrix
+    from xcolumns_amd.metrics import macro_recall_on_conf_matrix
+    from xcolumns_amd.weighted_prediction import predict_optimizing_macro_recall, predict_top_k
+    rng = np.random.default_rng(17)
+    n, m, k = 6000, 400, 3
+    w = 0.03 + 0.97 * rng.random(m) ** 3                       # skewed label priors
+    dense_proba = ((rng.random((n, m)) ** 4) * w).astype(np.float32)
+    dense_true = (rng.random((n, m)) < dense_proba).astype(np.float32)
+    scores = {}
+    for kind, conv in (("numpy", lambda x: x), ("csr", lambda x: csr_matrix(x)), ("torch", lambda x: torch.from_numpy(x).cuda())):
+        y_proba, y_true = conv(dense_proba), conv(dense_true)
+        y_pred, meta = predict_optimizing_macro_recall_using_bc(y_proba, k, return_meta=True, seed=2024)
+        assert type(y_pred) == type(y_proba) and y_pred.dtype == y_proba.dtype
+        rows = y_pred.sum(axis=1) if kind != "torch" else y_pred.sum(dim=1).cpu().numpy()
+        assert (np.asarray(rows).ravel() == k).all()
+        C = calculate_confusion_matrix(y_true, y_pred, normalize=False, skip_tn=False)
+        scores[kind] = float(macro_recall_on_conf_matrix(*C))
+    assert abs(scores["numpy"] - scores["torch"]) < 1e-6 and abs(scores["numpy"] - scores["csr"]) < 5e-3
+    top = float(macro_recall_on_conf_matrix(*calculate_confusion_matrix(dense_true, predict_top_k(dense_proba, k))))
+    opt = float(macro_recall_on_conf_matrix(*calculate_confusion_matrix(
+        dense_true, predict_optimizing_macro_recall(dense_proba, k, priors=dense_true.mean(axis=0)))))
+    print(f"top-k {top:.4f}  BCA {scores}  closed form {opt:.4f}")
+    assert scores["numpy"] >= top and abs(opt - scores["numpy"]) < 0.02
