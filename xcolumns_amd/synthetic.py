@@ -14,6 +14,7 @@ WORKLOADS = {
     "c3_amazon670k_150Kx670K": (150_000, 670_000),
     "c4_wiki500k_780Kx500K": (780_000, 500_000),
     "ns_1Mx500K": (1_000_000, 500_000),
+    "c5_amazon3m_1.7Mx2.8M": (1_700_000, 2_800_000),   # configs[4]'s shape (its workload is Frank-Wolfe: tools/fw_bench.py)
 }
 
 
