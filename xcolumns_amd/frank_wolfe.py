@@ -529,11 +529,28 @@ def find_classifier_using_fw(
         log_info(f"  Starting iteration {i}/{max_iters} ...", verbose)
         old_utility = new_utility  # the utility at `stats` (:585-587)
         a_i, b_i = eng.next_classifier(stats)
-        A[i] = a_i.cpu().numpy() if isinstance(a_i, torch.Tensor) else a_i
-        B[i] = b_i.cpu().numpy() if isinstance(b_i, torch.Tensor) else b_i
-        stats_i = eng.confusion_of(a_i if isinstance(a_i, torch.Tensor) else A[i],
-                                   b_i if isinstance(b_i, torch.Tensor) else B[i])
+        on_device = isinstance(a_i, torch.Tensor)
+        if on_device:
+            # the host's copy of the float32 rows travels while the GPU predicts, counts and scans
+            if a_i.is_cuda:
+                if i == 1:
+                    stage = torch.empty((2, m), dtype=torch.float32).pin_memory()
+                    side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):   # a copy-engine stream of its own: the kernels do not queue behind it
+                    stage[0].copy_(a_i, non_blocking=True)
+                    stage[1].copy_(b_i, non_blocking=True)
+                    staged = torch.cuda.Event()
+                    staged.record(side)
+            else:
+                A[i], B[i] = a_i.numpy(), b_i.numpy()
+        else:
+            A[i], B[i] = a_i, b_i
+        stats_i = eng.confusion_of(a_i if on_device else A[i], b_i if on_device else B[i])
         utility_i = eng.utility(stats_i)
+        if on_device and a_i.is_cuda:
+            staged.synchronize()
+            A[i], B[i] = stage[0].numpy(), stage[1].numpy()   # copied into the tables (float32 rows)
         log_info(f"    Metric value of new (sub)classifier {i}: {utility_i}", verbose)
         if search_for_best_alpha:
             alpha = eng.best_alpha(stats, stats_i, alpha_search_algo, alpha_tolerance, alpha_uniform_search_step)
