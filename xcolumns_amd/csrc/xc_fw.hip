@@ -173,6 +173,68 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
     if (live) partials[(int64_t)blockIdx.y * n_alpha + t] = sum;
 }
 
+// The long scan for the linear-fractional metrics (precision, recall, F-beta, Jaccard, plain or mixed with
+// precision@k): along the segment both numerator and denominator are linear in alpha,
+//   psi_j(alpha) = (N0 + alpha dN) / (D0 + alpha dD)  [+ L0 + alpha dL for the mixed utilities],
+// so the six per-label constants are formed once while the tile is staged and an evaluation is two (three)
+// fmas and one ~1-ulp division -- about half the float64 instructions of the general fast path, again within
+// the rounding differences the scan already has against numpy's pairwise sums.
+template <int BASE>
+__global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_linfrac_kernel(int64_t m, const double *cur,
+                                                                           const double *nxt, xc_metric metric,
+                                                                           int n_alpha, const double *alphas,
+                                                                           int64_t per_chunk, double *partials) {
+    __shared__ double s_c[XC_FW_TILE][6]; // N0, dN, D0, dD, L0, dL
+    const int t = blockIdx.x * XC_FW_TILE + threadIdx.x;
+    const bool live = t < n_alpha;
+    const double alpha = live ? alphas[t] : 0.0;
+    const int64_t j0 = (int64_t)blockIdx.y * per_chunk;
+    const int64_t j1 = (j0 + per_chunk < m) ? j0 + per_chunk : m;
+    const bool mixed = metric.mixed != 0;
+    const double eps = metric.epsilon, b2 = metric.beta * metric.beta;
+    const double scale = mixed ? metric.alpha / metric.mf : 1.0;      // frank_wolfe.py:832-838
+    const double lin = mixed ? (1.0 - metric.alpha) / metric.kf : 0.0;
+    double sum = 0.0;
+    for (int64_t base = j0; base < j1; base += XC_FW_TILE) {
+        const int64_t j = base + threadIdx.x;
+        const int cnt = (int)((j1 - base < XC_FW_TILE) ? j1 - base : XC_FW_TILE);
+        __syncthreads();
+        if (j < j1) {
+            const double tp = cur[j], fp = cur[m + j], fn = cur[2 * m + j];
+            const double dtp = nxt[j] - tp, dfp = nxt[m + j] - fp, dfn = nxt[2 * m + j] - fn;
+            double N0, dN, D0, dD;
+            if (BASE == XC_M_PRECISION) {
+                N0 = tp, dN = dtp, D0 = tp + fp + eps, dD = dtp + dfp;
+            } else if (BASE == XC_M_RECALL) {
+                N0 = tp, dN = dtp, D0 = tp + fn + eps, dD = dtp + dfn;
+            } else if (BASE == XC_M_FBETA) {
+                N0 = (1.0 + b2) * tp, dN = (1.0 + b2) * dtp;
+                D0 = (b2 * (tp + fp)) + tp + fn + eps, dD = (b2 * (dtp + dfp)) + dtp + dfn;
+            } else { // XC_M_JACCARD
+                N0 = tp, dN = dtp, D0 = tp + fp + fn + eps, dD = dtp + dfp + dfn;
+            }
+            s_c[threadIdx.x][0] = N0 * scale;
+            s_c[threadIdx.x][1] = dN * scale;
+            s_c[threadIdx.x][2] = D0;
+            s_c[threadIdx.x][3] = dD;
+            s_c[threadIdx.x][4] = lin * tp;
+            s_c[threadIdx.x][5] = lin * dtp;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll 4
+            for (int i = 0; i < cnt; ++i) {
+                const double n = __builtin_fma(alpha, s_c[i][1], s_c[i][0]);
+                const double d = __builtin_fma(alpha, s_c[i][3], s_c[i][2]);
+                double v = fdiv<false>(n, d);
+                if (mixed) v += __builtin_fma(alpha, s_c[i][5], s_c[i][4]);
+                sum += v;
+            }
+        }
+    }
+    if (live) partials[(int64_t)blockIdx.y * n_alpha + t] = sum;
+}
+
 } // namespace xc
 
 extern "C" {
@@ -217,18 +279,24 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_
         hipLaunchKernelGGL((xc::fw_alpha_curve_kernel<false, B>), dim3(gx, chunks), dim3(XC_FW_TILE), 0, st, m, cur, \
                            nxt, *metric_host, n_alpha, alphas, per_chunk, partials);                               \
         break
+#define XC_FW_SCAN_LINFRAC(B)                                                                                      \
+    case B:                                                                                                        \
+        hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B>), dim3(gx, chunks), dim3(XC_FW_TILE), 0, st, m, cur, \
+                           nxt, *metric_host, n_alpha, alphas, per_chunk, partials);                               \
+        break
         switch (metric_host->base) {
             XC_FW_SCAN(XC_M_PRECISION_AT_K);
-            XC_FW_SCAN(XC_M_PRECISION);
-            XC_FW_SCAN(XC_M_RECALL);
-            XC_FW_SCAN(XC_M_FBETA);
-            XC_FW_SCAN(XC_M_JACCARD);
+            XC_FW_SCAN_LINFRAC(XC_M_PRECISION);
+            XC_FW_SCAN_LINFRAC(XC_M_RECALL);
+            XC_FW_SCAN_LINFRAC(XC_M_FBETA);
+            XC_FW_SCAN_LINFRAC(XC_M_JACCARD);
             XC_FW_SCAN(XC_M_BALANCED_ACC);
             XC_FW_SCAN(XC_M_GMEAN);
             XC_FW_SCAN(XC_M_HMEAN);
             XC_FW_SCAN(XC_M_ACCURACY);
             XC_FW_SCAN(XC_M_RECALL_PRECISION_MIX);
         }
+#undef XC_FW_SCAN_LINFRAC
 #undef XC_FW_SCAN
     }
     XC_CHECK_LAUNCH("fw_alpha_curve_kernel");
