@@ -435,6 +435,13 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt,
                       const xc_metric *metric_host, int n_alpha, const double *alphas,
                       double *partials, void *stream);
 
+/* Counts for BINARY y_true (sorted distinct column ids per row, values all 1) against a
+ * fixed-stride 0/1 prediction of k DISTINCT labels per row: tp[j] += rows that predict and hold
+ * label j, cnt[j] += rows that predict j.  Then fp = cnt - tp and fn = (label count of y_true) - tp:
+ * the same numbers as xc_confusion_csr with less than half its atomics (the Frank-Wolfe iteration). */
+int xc_confusion_counts_csr(int64_t n, int k, const int32_t *t_indptr, const int32_t *t_indices,
+                            const int32_t *p_indices, double *tp, double *cnt, void *stream);
+
 /* xc_topk_csr with the weights interleaved, ab[2 col] = a[col], ab[2 col + 1] = b[col]
  * (y_proba's dtype): one gather per candidate instead of two.  Same gains bit for bit. */
 int xc_topk_csr_ab(int64_t n, const int32_t *indptr, const int32_t *indices, const void *data,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "xc_fw_gradient": (c_int, [c_int64, c_void_p, POINTER(XcMetric), c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "xc_fw_alpha_chunks": (c_int, [c_int64]),
     "xc_fw_alpha_curve": (c_int, [c_int64, c_void_p, c_void_p, POINTER(XcMetric), c_int, c_void_p, c_void_p, c_void_p]),
+    "xc_confusion_counts_csr": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_topk_csr_ab": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_topk_csr_rowwise": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -165,6 +165,13 @@ class FwEngine:
             if self.k > 0:  # every classifier's prediction has the same fixed-stride frame
                 self._pred_indptr = (torch.arange(self.n + 1, device=self.dev, dtype=torch.int64) * self.k).to(torch.int32)
                 self._pred_ones = torch.ones(self.n * self.k, dtype=self.stat_dtype, device=self.dev)
+            # binary labels, k distinct predictions per row, no padded rows: tp and per-label counts are
+            # enough (fp = count - tp, fn = label count - tp; xc_confusion_counts_csr)
+            row_nnz = np.diff(y_proba.indptr)
+            self._counts_path = bool(self.k > 0 and self.n > 0 and row_nnz.min() >= self.k
+                                     and bool((self.true.data == 1).all().item()) and yt.has_sorted_indices)
+            if self._counts_path:
+                self._true_count = torch.bincount(self.true.indices, minlength=self.m).to(torch.float64)
         else:
             yt = y_true if isinstance(y_true, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_true))
             yp = y_proba if isinstance(y_proba, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_proba))
@@ -191,12 +198,20 @@ class FwEngine:
                 c = self.proba
                 _lib.call("xc_topk_csr_ab", c.n, D.ptr(c.indptr), D.ptr(c.indices), D.ptr(c.data), c.code,
                           int(c.max_row_nnz), self.k, D.ptr(ab), 0, D.ptr(idx), None, None, None, D.stream())
-                pred = D.DeviceCSR(self._pred_indptr, idx, self._pred_ones, (self.n, self.m), self.k)
+                if self._counts_path:
+                    tc = torch.zeros((2, self.m), dtype=torch.float64, device=self.dev)
+                    _lib.call("xc_confusion_counts_csr", self.n, self.k, D.ptr(self.true.indptr), D.ptr(self.true.indices),
+                              D.ptr(idx), D.ptr(tc[0]), D.ptr(tc[1]), D.stream())
+                    counts = torch.stack((tc[0], tc[1] - tc[0], self._true_count - tc[0]))
+                    pred = None
+                else:
+                    pred = D.DeviceCSR(self._pred_indptr, idx, self._pred_ones, (self.n, self.m), self.k)
             else:
                 indptr, idx = threshold_csr_device(self.proba, 0.0, a_d, b_d)
                 ones = torch.ones(max(1, idx.numel()), dtype=self.stat_dtype, device=self.dev)
                 pred = D.DeviceCSR(indptr, idx, ones, (self.n, self.m), 0)
-            counts = confusion_csr_device(self.true, pred)
+            if pred is not None:
+                counts = confusion_csr_device(self.true, pred)
         else:
             gains = self.proba * D.to_device(a, device=self.dev) + D.to_device(b, device=self.dev)  # :37-41
             D.dtype_code(gains.dtype)
