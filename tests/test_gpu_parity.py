@@ -348,6 +348,18 @@ def test_api_contract_and_errors():
         predict_weighted_per_instance(Yd, "2")
     with pytest.raises(ValueError):
         predict_weighted_per_instance(np.zeros((2, 2, 2)), 1)
+    # column ids outside [0, m) never reach a kernel (scipy does not validate them)
+    bad = csr_matrix(Yd)
+    bad.indices = bad.indices.copy()
+    bad.indices[7] = 12
+    with pytest.raises(ValueError, match="column ids"):
+        predict_top_k(bad, 2)
+    with pytest.raises(ValueError, match="column ids"):
+        predict_using_bc_with_0approx(bad, binary_recall_on_conf_matrix, 2)
+    init = predict_top_k(csr_matrix(Yd), 2)
+    init.indices[3] = -1
+    with pytest.raises(ValueError, match="column ids"):
+        predict_using_bc_with_0approx(csr_matrix(Yd), binary_recall_on_conf_matrix, 2, init_y_pred=init)
     # 1-d input is one row (weighted_prediction.py:142-143)
     one = predict_top_k(Yd[0], 3)
     assert one.shape == (1, 12) and one.sum() == 3

@@ -72,6 +72,17 @@ def to_device(a, dtype=None, device=None) -> torch.Tensor:
     return t.contiguous()
 
 
+def check_column_ids(indices: torch.Tensor, m: int, what: str) -> None:
+    """The kernels index m-length tables with these ids unchecked: refuse ids outside [0, m) here, before
+    any launch (one min/max pass on the device; scipy itself does not validate `indices`)."""
+    if indices.numel() == 0:
+        return
+    lo, hi = torch.aminmax(indices)
+    lo, hi = int(lo), int(hi)
+    if lo < 0 or hi >= m:
+        raise ValueError(f"{what}: column ids must lie in [0, {m}), found [{lo}, {hi}]")
+
+
 @dataclass
 class DeviceCSR:
     """A CSR matrix resident in HBM: int32 indptr / indices, float data."""
@@ -105,10 +116,16 @@ class DeviceCSR:
             raise ValueError("matrices with >= 2^31 stored entries are not supported (int32 offsets)")
         dtype_code(mat.dtype)
         indptr = np.ascontiguousarray(mat.indptr, dtype=np.int32)
-        max_row = int(np.diff(indptr).max()) if mat.shape[0] > 0 else 0
+        row_nnz = np.diff(indptr)
+        if indptr.size != mat.shape[0] + 1 or indptr[0] != 0 or indptr[-1] != mat.indices.size or \
+                (row_nnz.size and row_nnz.min() < 0) or mat.data.size != mat.indices.size:
+            raise ValueError("malformed csr_matrix: indptr must start at 0, be non-decreasing and end at nnz")
+        max_row = int(row_nnz.max()) if mat.shape[0] > 0 else 0
+        indices = torch.from_numpy(np.ascontiguousarray(mat.indices, dtype=np.int32)).to(device)
+        check_column_ids(indices, int(mat.shape[1]), "csr_matrix")
         return DeviceCSR(
             indptr=torch.from_numpy(indptr).to(device),
-            indices=torch.from_numpy(np.ascontiguousarray(mat.indices, dtype=np.int32)).to(device),
+            indices=indices,
             data=torch.from_numpy(np.ascontiguousarray(mat.data)).to(device),
             shape=tuple(int(x) for x in mat.shape),
             max_row_nnz=max_row,

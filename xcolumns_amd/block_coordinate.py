@@ -604,7 +604,9 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
     if init_idx is None:
         eng.init_top()
     else:
-        eng.init_indices(torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)))
+        init_dev = torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)).to(dev)
+        D.check_column_ids(init_dev, m, "init_y_pred")
+        eng.init_indices(init_dev)
 
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
     if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
@@ -898,6 +900,7 @@ def predict_optimizing_coverage_using_bc(
         pred_idx, _, pred_eta = topk_csr_device(csr, k, want_eta=True, out_sel=sel)
     else:
         pred_idx = torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)).to(dev)
+        D.check_column_ids(pred_idx, m, "init_y_pred")
         pred_eta = torch.empty(n * k, dtype=csr.data.dtype, device=dev)
         orphans = torch.empty(n * k, dtype=torch.int32, device=dev)
         _lib.call("xc_bca_gather_pred_eta", n, D.ptr(csr.indptr), D.ptr(csr.indices), D.ptr(csr.data), csr.code,

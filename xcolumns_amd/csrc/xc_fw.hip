@@ -15,6 +15,7 @@
 #include "xc_host.h"
 
 #define XC_FW_TILE 256
+#define XC_FW_MAX_CHUNKS 128 /* label chunks of the step scan (grid y) */
 #define XC_FW_EXACT_POINTS 16 /* up to this many alphas: the reference's exact arithmetic */
 
 namespace xc {
@@ -179,22 +180,28 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
 // so the six per-label constants are formed once while the tile is staged and an evaluation is two (three)
 // fmas and one ~1-ulp division -- about half the float64 instructions of the general fast path, again within
 // the rounding differences the scan already has against numpy's pairwise sums.
-template <int BASE>
+// Every thread carries A step sizes: the six constants of a label are read from LDS once per A evaluations
+// (one step size per thread makes the scan LDS-bound: 32-48 B of broadcast reads per ~13 float64 instructions).
+template <int BASE, int A>
 __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_linfrac_kernel(int64_t m, const double *cur,
                                                                            const double *nxt, xc_metric metric,
                                                                            int n_alpha, const double *alphas,
                                                                            int64_t per_chunk, double *partials) {
     __shared__ double s_c[XC_FW_TILE][6]; // N0, dN, D0, dD, L0, dL
-    const int t = blockIdx.x * XC_FW_TILE + threadIdx.x;
-    const bool live = t < n_alpha;
-    const double alpha = live ? alphas[t] : 0.0;
+    int t[A];
+    double alpha[A], sum[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        t[a] = (blockIdx.x * A + a) * XC_FW_TILE + threadIdx.x;
+        alpha[a] = t[a] < n_alpha ? alphas[t[a]] : 0.0;
+        sum[a] = 0.0;
+    }
     const int64_t j0 = (int64_t)blockIdx.y * per_chunk;
     const int64_t j1 = (j0 + per_chunk < m) ? j0 + per_chunk : m;
     const bool mixed = metric.mixed != 0;
     const double eps = metric.epsilon, b2 = metric.beta * metric.beta;
     const double scale = mixed ? metric.alpha / metric.mf : 1.0;      // frank_wolfe.py:832-838
     const double lin = mixed ? (1.0 - metric.alpha) / metric.kf : 0.0;
-    double sum = 0.0;
     for (int64_t base = j0; base < j1; base += XC_FW_TILE) {
         const int64_t j = base + threadIdx.x;
         const int cnt = (int)((j1 - base < XC_FW_TILE) ? j1 - base : XC_FW_TILE);
@@ -221,18 +228,25 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_linfrac_kernel(int6
             s_c[threadIdx.x][5] = lin * dtp;
         }
         __syncthreads();
-        if (live) {
-#pragma unroll 4
-            for (int i = 0; i < cnt; ++i) {
-                const double n = __builtin_fma(alpha, s_c[i][1], s_c[i][0]);
-                const double d = __builtin_fma(alpha, s_c[i][3], s_c[i][2]);
-                double v = fdiv<false>(n, d);
-                if (mixed) v += __builtin_fma(alpha, s_c[i][5], s_c[i][4]);
-                sum += v;
+#pragma unroll 2
+        for (int i = 0; i < cnt; ++i) {
+            const double N0 = s_c[i][0], dN = s_c[i][1], D0 = s_c[i][2], dD = s_c[i][3];
+            if (mixed) {
+                const double L0 = s_c[i][4], dL = s_c[i][5];
+#pragma unroll
+                for (int a = 0; a < A; ++a)
+                    sum[a] += fdiv<false>(__builtin_fma(alpha[a], dN, N0), __builtin_fma(alpha[a], dD, D0)) +
+                              __builtin_fma(alpha[a], dL, L0);
+            } else {
+#pragma unroll
+                for (int a = 0; a < A; ++a)
+                    sum[a] += fdiv<false>(__builtin_fma(alpha[a], dN, N0), __builtin_fma(alpha[a], dD, D0));
             }
         }
     }
-    if (live) partials[(int64_t)blockIdx.y * n_alpha + t] = sum;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+        if (t[a] < n_alpha) partials[(int64_t)blockIdx.y * n_alpha + t[a]] = sum[a];
 }
 
 } // namespace xc
@@ -253,7 +267,7 @@ int xc_fw_gradient(int64_t m, const double *stats, const xc_metric *metric_host,
 
 int xc_fw_alpha_chunks(int64_t m) {
     const int64_t tiles = (m + XC_FW_TILE - 1) / XC_FW_TILE;
-    return (int)(tiles < 1 ? 1 : (tiles > 64 ? 64 : tiles));
+    return (int)(tiles < 1 ? 1 : (tiles > XC_FW_MAX_CHUNKS ? XC_FW_MAX_CHUNKS : tiles));
 }
 
 int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_metric *metric_host, int n_alpha,
@@ -281,8 +295,13 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_
         break
 #define XC_FW_SCAN_LINFRAC(B)                                                                                      \
     case B:                                                                                                        \
-        hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B>), dim3(gx, chunks), dim3(XC_FW_TILE), 0, st, m, cur, \
-                           nxt, *metric_host, n_alpha, alphas, per_chunk, partials);                               \
+        if (n_alpha >= 4 * XC_FW_TILE)                                                                             \
+            hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B, 4>), dim3((gx + 3) / 4, chunks),              \
+                               dim3(XC_FW_TILE), 0, st, m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk,     \
+                               partials);                                                                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B, 1>), dim3(gx, chunks), dim3(XC_FW_TILE), 0,   \
+                               st, m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials);               \
         break
         switch (metric_host->base) {
             XC_FW_SCAN(XC_M_PRECISION_AT_K);

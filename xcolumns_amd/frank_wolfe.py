@@ -267,10 +267,8 @@ class FwEngine:
         part = torch.empty((chunks, n_alpha), dtype=torch.float64, device=self.dev)
         _lib.call("xc_fw_alpha_curve", m, D.ptr(c), D.ptr(x), ctypes.byref(self.metric), n_alpha, D.ptr(al),
                   D.ptr(part), D.stream())
-        vals = part[0].clone()
-        for ci in range(1, chunks):  # fixed order: the result does not depend on the launch
-            vals += part[ci]
-        return vals.cpu().numpy()
+        # one reduction kernel over the chunk axis (no atomics: the same result on every run)
+        return part.sum(dim=0).cpu().numpy()
 
     def best_alpha(self, cur, nxt, algo: str, eps: float, step: float):
         """_find_best_alpha, frank_wolfe.py:379-404."""
