@@ -663,7 +663,46 @@ def gen_io():
     save("io", **out)
 
 
+def gen_api():
+    """The public surface of the reference's library modules as data: every module-level public name, and for
+    plain ``def``s the parameter names with their literal defaults (read with ``ast``; wrappers produced by
+    factories are listed by name only)."""
+    import ast
+    api = {}
+    for mod in ("metrics", "block_coordinate", "weighted_prediction", "frank_wolfe", "confusion_matrix", "utils", "types"):
+        tree = ast.parse(open(os.path.join(REFERENCE, "xcolumns", mod + ".py")).read())
+        entry = {}
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef) and not node.name.startswith("_"):
+                a = node.args
+                names = [x.arg for x in a.posonlyargs + a.args]
+                defaults = [None] * (len(names) - len(a.defaults)) + list(a.defaults)
+                params = []
+                for nm, d in zip(names, defaults):
+                    item = {"name": nm}
+                    if isinstance(d, ast.Constant):
+                        item["default"] = d.value
+                    params.append(item)
+                for x, d in zip(a.kwonlyargs, a.kw_defaults):
+                    item = {"name": x.arg}
+                    if isinstance(d, ast.Constant):
+                        item["default"] = d.value
+                    params.append(item)
+                entry[node.name] = {"kind": "def", "params": params, "var_kw": a.kwarg is not None}
+            elif isinstance(node, ast.ClassDef) and not node.name.startswith("_"):
+                entry[node.name] = {"kind": "class", "methods": sorted(
+                    n.name for n in node.body if isinstance(n, ast.FunctionDef) and not n.name.startswith("_"))}
+            elif isinstance(node, ast.Assign):
+                for tg in node.targets:
+                    if isinstance(tg, ast.Name) and not tg.id.startswith("_"):
+                        entry[tg.id] = {"kind": "name"}
+        api[mod] = entry
+    with open(os.path.join(HERE, "public_api.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print("public_api.json:", {k: len(v) for k, v in api.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage", "io"]
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage", "io", "api"]
     for w in which:
         globals()["gen_" + w]()

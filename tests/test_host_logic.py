@@ -87,6 +87,33 @@ def test_wrapper_signatures_expose_kwargs():
     assert inspect.signature(bc.predict_optimizing_instance_precision_using_bc).parameters["init_y_pred"].default == "random"
 
 
+def test_public_surface_of_the_reference_is_present():
+    """tests/golden/public_api.json lists every public module-level name of the reference's library modules
+    (generated from its sources by make_golden.py): each exists here, plain functions take the same
+    parameters in the same order with the same literal defaults, classes have the same public methods."""
+    import importlib
+    import json
+    import os
+    api = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "public_api.json")))
+    assert sum(len(v) for v in api.values()) > 150
+    for mod, entry in api.items():
+        module = importlib.import_module("xcolumns_amd." + mod)
+        for name, info in entry.items():
+            assert hasattr(module, name), f"{mod}.{name} is missing"
+            obj = getattr(module, name)
+            if info["kind"] == "class":
+                for meth in info["methods"]:
+                    assert hasattr(obj, meth), f"{mod}.{name}.{meth} is missing"
+            elif info["kind"] == "def":
+                params = inspect.signature(obj).parameters
+                mine = [p.name for p in params.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+                ref = [p["name"] for p in info["params"]]
+                assert mine[:len(ref)] == ref, f"{mod}.{name}: {mine} vs {ref}"
+                for p in info["params"]:
+                    if "default" in p:
+                        assert params[p["name"]].default == p["default"], f"{mod}.{name}({p['name']})"
+
+
 def test_order_stream_is_the_reference_stream():
     """block_coordinate.py:413-419: one Generator, cumulative in-place shuffles."""
     src = bc._OrderSource.__new__(bc._OrderSource)

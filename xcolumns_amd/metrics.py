@@ -265,13 +265,13 @@ def make_macro_metric_on_conf_matrix(binary_metric: Callable, name: str) -> Call
     return _with_kwargs_of(macro_metric_on_conf_matrix, binary_metric)
 
 
-def make_micro_metric_on_conf_matrix(binary_metric: Callable, name: str) -> Callable:
+def make_micro_metric_on_conf_matrix(binary_metric: Callable, metric_name: str) -> Callable:
     """`binary_metric` of the label-summed entries."""
 
     def micro_metric_on_conf_matrix(tp, fp, fn, tn, **kwargs):
         return binary_metric(tp.sum(), fp.sum(), fn.sum(), tn.sum(), **kwargs)
 
-    micro_metric_on_conf_matrix.__doc__ = f"Micro-averaged {name}: {binary_metric.__name__} of the summed entries."
+    micro_metric_on_conf_matrix.__doc__ = f"Micro-averaged {metric_name}: {binary_metric.__name__} of the summed entries."
     return _with_kwargs_of(micro_metric_on_conf_matrix, binary_metric)
 
 
