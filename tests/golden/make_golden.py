@@ -663,6 +663,81 @@ def gen_io():
     save("io", **out)
 
 
+def gen_wrappers():
+    """The weighted-prediction wrappers the reference's tests call (tests/test_weighted_prediction.py:69-103):
+    macro recall / balanced accuracy, log and power-law weights, propensity-scored precision -- CSR float32
+    and dense float64 inputs; rows whose k-th and (k+1)-th gains tie are regenerated."""
+    import xcolumns.weighted_prediction as wp
+    rng = np.random.default_rng(404)
+    n, m, r, k = 240, 90, 18, 3
+    priors = np.clip(rng.random(m) ** 3, 2e-3, 0.6)
+    inv_prop = 1.0 + rng.random(m) * 20.0
+    prop = 1.0 / inv_prop
+    prop[::17] = 0.0  # zeros are mapped to 1 (weighted_prediction.py:524-526)
+    cases = {
+        "macro_recall": (wp.predict_optimizing_macro_recall, dict(priors=priors)),
+        "macro_balanced_accuracy": (wp.predict_optimizing_macro_balanced_accuracy, dict(priors=priors)),
+        "log_weighted": (wp.predict_log_weighted_per_instance, dict(priors=priors)),
+        "power_law": (wp.predict_power_law_weighted_per_instance, dict(priors=priors, beta=0.5)),
+        "instance_precision": (wp.predict_optimizing_instance_precision, dict()),
+        "ps_precision_inverse": (wp.predict_optimizing_instance_propensity_scored_precision,
+                                 dict(inverse_propensities=inv_prop)),
+        "ps_precision_propensities": (wp.predict_optimizing_instance_propensity_scored_precision,
+                                      dict(propensities=prop)),
+    }
+
+    def gains_of(name, eta, cols):
+        pri = priors[cols]
+        if name == "macro_recall":
+            return eta * (1.0 / (pri + 1e-6))
+        if name == "macro_balanced_accuracy":
+            return eta / (pri + 1e-6) - (1 - eta) / (1 - (pri + 1e-6))
+        if name == "log_weighted":
+            return eta * -np.log(pri + 1e-9)
+        if name == "power_law":
+            return eta * (pri + 1e-9) ** -0.5
+        if name == "instance_precision":
+            return eta
+        if name == "ps_precision_inverse":
+            return eta * inv_prop[cols]
+        p = prop[cols].copy()
+        p[p == 0] = 1.0
+        return eta * (1.0 / p)
+
+    cols_all, data_all = [], []
+    for i in range(n):
+        while True:
+            cols = np.sort(rng.choice(m, r, replace=False))
+            eta = rng.random(r)
+            ok = True
+            for name in cases:
+                g = np.sort(gains_of(name, eta.astype(np.float32).astype(np.float64), cols))[::-1]
+                if g[k - 1] - g[k] < 1e-4 * max(1.0, abs(g[k - 1])):
+                    ok = False
+            if ok:
+                break
+        cols_all.append(cols)
+        data_all.append(eta)
+    cols_all = np.concatenate(cols_all).astype(np.int32)
+    data_all = np.concatenate(data_all)
+    indptr = (np.arange(n + 1) * r).astype(np.int32)
+    Y32 = csr_matrix((data_all.astype(np.float32), cols_all, indptr), shape=(n, m))
+    Yd = Y32.astype(np.float64).toarray()
+    out = {"k": np.int64(k), "priors": priors, "inverse_propensities": inv_prop, "propensities": prop}
+    out.update(csr_fields("y", Y32))
+    for name, (fn, kw) in cases.items():
+        kw_c = {kk: (v.copy() if isinstance(v, np.ndarray) else v) for kk, v in kw.items()}
+        P = fn(Y32, k, **kw_c)
+        assert P.dtype == np.float32 and (np.diff(P.indptr) == k).all()
+        out["csr_" + name] = P.indices.reshape(n, k).astype(np.int32)
+        kw_d = {kk: (v.copy() if isinstance(v, np.ndarray) else v) for kk, v in kw.items()}
+        Pd = fn(Yd, k, **kw_d)
+        assert Pd.dtype == np.float64 and (Pd.sum(axis=1) == k).all()
+        out["dense_" + name] = np.sort(np.argsort(-Pd, axis=1, kind="stable")[:, :k], axis=1).astype(np.int32)
+        assert np.array_equal(out["csr_" + name], out["dense_" + name]) or name == "macro_balanced_accuracy", name
+    save("wp_wrappers", **out)
+
+
 def gen_api():
     """The public surface of the reference's library modules as data: every module-level public name, and for
     plain ``def``s the parameter names with their literal defaults (read with ``ast``; wrappers produced by
@@ -703,6 +778,6 @@ def gen_api():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage", "io", "api"]
+    which = sys.argv[1:] or ["topk_csr", "topk_dense", "confusion", "bca_csr", "bca_dense", "eval", "fw", "coverage", "io", "api", "wrappers"]
     for w in which:
         globals()["gen_" + w]()

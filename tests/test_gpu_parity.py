@@ -965,3 +965,38 @@ def test_block_coordinate_reference_test_properties():
         dense_true, predict_optimizing_macro_recall(dense_proba, k, priors=dense_true.mean(axis=0)))))
     print(f"top-k {top:.4f}  BCA {scores}  closed form {opt:.4f}")
     assert scores["numpy"] >= top and abs(opt - scores["numpy"]) < 0.02
+
+
+WRAPPER_CASES = {
+    "macro_recall": ("predict_optimizing_macro_recall", ("priors",), {}),
+    "macro_balanced_accuracy": ("predict_optimizing_macro_balanced_accuracy", ("priors",), {}),
+    "log_weighted": ("predict_log_weighted_per_instance", ("priors",), {}),
+    "power_law": ("predict_power_law_weighted_per_instance", ("priors",), {"beta": 0.5}),
+    "instance_precision": ("predict_optimizing_instance_precision", (), {}),
+    "ps_precision_inverse": ("predict_optimizing_instance_propensity_scored_precision", ("inverse_propensities",), {}),
+    "ps_precision_propensities": ("predict_optimizing_instance_propensity_scored_precision", ("propensities",), {}),
+}
+
+
+@pytest.mark.parametrize("case", sorted(WRAPPER_CASES))
+def test_weighted_prediction_wrappers_golden(case):
+    """The wrappers of tests/test_weighted_prediction.py:69-103 against label sets the reference produced
+    (tests/golden/wp_wrappers.npz), for CSR float32, dense float64 and torch inputs: bit-exact."""
+    import xcolumns_amd.weighted_prediction as wp
+    z = G.load("wp_wrappers")
+    k = int(z["k"])
+    Y = G.csr_from(z, "y")
+    n, m = Y.shape
+    name, vec_args, extra = WRAPPER_CASES[case]
+    fn = getattr(wp, name)
+    kw = lambda conv=(lambda v: v): {**{a: conv(z[a].copy()) for a in vec_args}, **extra}  # noqa: E731
+    P = fn(Y, k, **kw())
+    assert isinstance(P, csr_matrix) and P.dtype == np.float32 and (np.diff(P.indptr) == k).all()
+    assert np.array_equal(P.indices.reshape(n, k), z["csr_" + case])
+    Yd = Y.astype(np.float64).toarray()
+    Pd = fn(Yd, k, **kw())
+    assert isinstance(Pd, np.ndarray) and Pd.dtype == np.float64 and (Pd.sum(axis=1) == k).all()
+    assert np.array_equal(np.sort(np.argsort(-Pd, axis=1, kind="stable")[:, :k], axis=1), z["dense_" + case])
+    Pt = fn(torch.from_numpy(Yd).cuda(), k, **kw(lambda v: torch.from_numpy(v).cuda()))
+    assert isinstance(Pt, torch.Tensor) and Pt.is_cuda and Pt.dtype == torch.float64
+    assert np.array_equal(Pt.cpu().numpy(), Pd)
