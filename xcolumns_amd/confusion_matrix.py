@@ -156,12 +156,25 @@ def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
         home = None
         is_torch = False
 
+    # dtype=None: CSR results take y_true's dtype (confusion_matrix.py:184, :214, :228); dense ones the dtype
+    # of the summed product, i.e. numpy's promotion of the two inputs (:166, :193, :202)
+    if dense and is_torch:
+        default = torch.result_type(y_true, y_pred) if isinstance(y_pred, torch.Tensor) else y_true.dtype
+    elif dense:
+        default = np.result_type(y_true.dtype, y_pred.dtype if hasattr(y_pred, "dtype") else np.float64)
+        if default.kind in "bi":
+            default = np.dtype(np.int64)
+        elif default.kind == "u":
+            default = np.dtype(np.uint64)
+    else:
+        default = D.numpy_dtype(y_true.dtype)
+
     def back(vec: torch.Tensor, dtype):
         if is_torch:
             v = vec.to(home)
-            return v.to(D.torch_dtype(dtype)) if dtype is not None else v.to(y_true.dtype)
+            return v.to(D.torch_dtype(dtype)) if dtype is not None else v.to(default)
         out = vec.cpu().numpy()
-        return out.astype(dtype if dtype is not None else D.numpy_dtype(y_true.dtype), copy=False)
+        return out.astype(dtype if dtype is not None else default, copy=False)
 
     return stats, back
 
