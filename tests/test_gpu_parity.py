@@ -1000,3 +1000,26 @@ def test_weighted_prediction_wrappers_golden(case):
     Pt = fn(torch.from_numpy(Yd).cuda(), k, **kw(lambda v: torch.from_numpy(v).cuda()))
     assert isinstance(Pt, torch.Tensor) and Pt.is_cuda and Pt.dtype == torch.float64
     assert np.array_equal(Pt.cpu().numpy(), Pd)
+
+
+@pytest.mark.parametrize("switch", ["XCOLUMNS_BCA_PACKED", "XCOLUMNS_BCA_HOT", "XCOLUMNS_BCA_SHADOW"])
+@pytest.mark.parametrize("waves", [1, None])
+def test_bca_csr_kernel_variants_behind_the_switches(oref, monkeypatch, switch, waves):
+    """The kernel variants a default run does not take for float32 scores -- the separate index / score
+    streams (what m > 2^25 labels fall back to), no hot-label table, the float64 records instead of their
+    float32 copy -- on skewed data (hot labels exist): with one wavefront each is the sequential oracle to
+    1e-12, with the default concurrency it meets the same bars as the default variant."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    n, m, r, k = 20000, 3000, 30, 5
+    Y = _synthetic_csr(n, m, r, 12, zipf=True)
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=3, max_iters=4, tolerance=-1.0)
+    monkeypatch.setenv(switch, "0")
+    Pg, mg = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=3, max_iters=4, tolerance=-1.0, return_meta=True,
+                                                        bca_waves=waves)
+    diff = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print(switch, waves, diff)
+    if waves == 1:
+        assert diff.max() < 1e-12 and np.array_equal(Pg.indices, Po.indices)
+    else:
+        assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL
