@@ -1023,3 +1023,28 @@ def test_bca_csr_kernel_variants_behind_the_switches(oref, monkeypatch, switch, 
         assert diff.max() < 1e-12 and np.array_equal(Pg.indices, Po.indices)
     else:
         assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL
+
+
+def test_bca_csr_label_space_beyond_the_packed_stream(oref):
+    """m = 40 M labels (> 2^25, the packed 16-byte entries hold 25-bit column ids): the sweep falls back to the
+    separate index / score streams by itself; record offsets stay within 32 bits.  Sequential = the oracle
+    to 1e-12, default concurrency within the bars."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
+    n, m, r, k = 3000, 40_000_000, 24, 3
+    rng = np.random.default_rng(77)
+    cols = np.sort(rng.integers(0, m, size=(n, r), dtype=np.int64), axis=1)
+    cols[:, -1] = m - 1 - rng.integers(0, 50, size=n)          # the far end of the tables is touched
+    cols = np.sort(cols, axis=1)
+    assert (np.diff(cols, axis=1) > 0).all()
+    Y = csr_matrix(((rng.random(n * r) ** 2).astype(np.float32).clip(1e-3, 1), cols.ravel().astype(np.int32),
+                    (np.arange(n + 1) * r).astype(np.int32)), shape=(n, m))
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=5, max_iters=2, tolerance=-1.0)
+    for waves in (1, None):
+        Pg, mg = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=5, max_iters=2, tolerance=-1.0,
+                                                            return_meta=True, bca_waves=waves)
+        diff = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+        if waves == 1:
+            assert diff.max() < 1e-12 and np.array_equal(Pg.indices, Po.indices)
+        else:
+            assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL
