@@ -218,3 +218,52 @@ def test_frank_wolfe_ragged_rows_vs_oracle():
         np.testing.assert_array_equal(pred.indptr, pred_o.indptr)
         np.testing.assert_array_equal(pred.indices, pred_o.indices)
         assert (np.diff(pred.indptr) == np.minimum(lens, k)).all()
+
+
+@pytest.mark.parametrize("base", ["PRECISION", "RECALL", "FBETA", "JACCARD"])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_step_scan_fast_path_matches_the_exact_expression(base, mixed):
+    """The long step scan (> 16 points: per-label linear-fractional form, reciprocal seeded from the
+    neighbouring step size where the denominator moves slowly) against the exact kernel (the reference's
+    expression with IEEE division, used for <= 16 points) at the same step sizes -- on labels that stress the
+    seed: denominators that start or end at epsilon, labels untouched by one of the two classifiers, identical
+    statistics, and a non-uniform grid."""
+    import ctypes
+    from xcolumns_amd import _device as D, _lib
+    from xcolumns_amd.metrics import MetricSpec
+    dev = D.require_gpu()
+    rng = np.random.default_rng(3)
+    m, n = 5000, 200000.0
+
+    def stats():
+        pred = rng.integers(0, 400, m).astype(np.float64)
+        pos = rng.integers(0, 300, m).astype(np.float64)
+        pred[rng.random(m) < 0.2] = 0            # never predicted: precision's denominator is epsilon
+        pos[rng.random(m) < 0.1] = 0             # no positives
+        tp = np.floor(np.minimum(pred, pos) * rng.random(m))
+        fp, fn = pred - tp, pos - tp
+        return np.stack([tp, fp, fn, n - tp - fp - fn]) / n
+
+    cur, nxt = stats(), stats()
+    nxt[:, :50] = cur[:, :50]                    # labels the step does not move
+    spec = MetricSpec(base=getattr(_lib, "XC_M_" + base), mixed=mixed, alpha=0.7, kf=3.0, mf=float(m)) if mixed \
+        else MetricSpec(base=getattr(_lib, "XC_M_" + base))
+    metric = spec.to_c()
+    grid = np.concatenate([[0.0], np.arange(1e-4, 1, 1e-4)])
+    grid[5000:] = np.sort(rng.random(grid.size - 5000))   # second half: irregular spacing
+    c_d, x_d = (torch.from_numpy(v).to(dev).contiguous() for v in (cur, nxt))
+
+    def curve(alphas):
+        chunks = int(_lib.load().xc_fw_alpha_chunks(m))
+        al = torch.from_numpy(np.ascontiguousarray(alphas)).to(dev)
+        part = torch.empty((chunks, alphas.size), dtype=torch.float64, device=dev)
+        _lib.call("xc_fw_alpha_curve", m, D.ptr(c_d), D.ptr(x_d), ctypes.byref(metric), int(alphas.size), D.ptr(al),
+                  D.ptr(part), D.stream())
+        return part.sum(dim=0).cpu().numpy()
+
+    fast = curve(grid)
+    picks = np.concatenate([np.arange(0, 64), rng.choice(grid.size, 192, replace=False), [grid.size - 1]])
+    exact = np.concatenate([curve(grid[picks[i:i + 16]]) for i in range(0, picks.size, 16)])
+    rel = np.abs(fast[picks] - exact) / np.abs(exact)
+    print(base, mixed, "max relative difference", rel.max())
+    assert rel.max() < 1e-12

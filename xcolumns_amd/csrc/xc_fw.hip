@@ -180,14 +180,38 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
 // so the six per-label constants are formed once while the tile is staged and an evaluation is two (three)
 // fmas and one ~1-ulp division -- about half the float64 instructions of the general fast path, again within
 // the rounding differences the scan already has against numpy's pairwise sums.
-// Every thread carries A step sizes: the six constants of a label are read from LDS once per A evaluations
-// (one step size per thread makes the scan LDS-bound: 32-48 B of broadcast reads per ~13 float64 instructions).
-template <int BASE, int A>
+// Every thread carries A step sizes, so a label's constants are read from LDS once per A evaluations, and
+// the evaluation itself is cut to its reciprocal.  While a tile is staged each label is put in one of three
+// classes:
+//   linear  dD == 0 (the step does not move the denominator; most labels of a large label space):
+//           psi = N0/D0 + alpha dN/D0 -- two per-label numbers that are summed over the labels ONCE and
+//           applied to every step size at the end; nothing per evaluation;
+//   smooth  psi = c1 + c2 / d(alpha) with c1 = dN/dD, c2 = N0 - c1 D0 (n - c1 d does not depend on alpha):
+//           c1 joins the per-label sums, an evaluation is d = fma(alpha, dD, D0), its reciprocal (v_rcp_f64 +
+//           two Newton steps) and one fma -- 7 float64 instructions instead of 9.  Taken when |c1| <= 64 and
+//           the two end-point denominators are within 1024x of each other, which bounds the cancellation in
+//           c1 + c2 r to ~1e-11 absolute per label (the label sums are O(m));
+//   rough   everything else (denominators that start or end near epsilon, 0/0): numerator * reciprocal.
+// The linear part of the mixed utilities, (1 - a)/k (tp + alpha dtp), is a per-label sum as well.  Smooth
+// labels are staged from the front of the tile, rough ones from the back: two branch-free loops.
+#define XC_FW_SMOOTH_C1 64.0
+#define XC_FW_SMOOTH_RATIO 1024.0
+__device__ __forceinline__ double fw_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+
+template <int BASE, int A, bool MIXED>
 __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_linfrac_kernel(int64_t m, const double *cur,
                                                                            const double *nxt, xc_metric metric,
                                                                            int n_alpha, const double *alphas,
                                                                            int64_t per_chunk, double *partials) {
-    __shared__ double s_c[XC_FW_TILE][6]; // N0, dN, D0, dD, L0, dL
+    constexpr int NW = XC_FW_TILE / XC_WAVE;
+    __shared__ double s_c[XC_FW_TILE][4]; // smooth: c2, -, D0, dD   rough: N0, dN, D0, dD
+    __shared__ double s_lin[NW][2];
+    __shared__ int s_smooth[NW], s_rough[NW];
+    const int lane = threadIdx.x & (XC_WAVE - 1), wave = threadIdx.x / XC_WAVE;
     int t[A];
     double alpha[A], sum[A];
 #pragma unroll
@@ -198,18 +222,17 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_linfrac_kernel(int6
     }
     const int64_t j0 = (int64_t)blockIdx.y * per_chunk;
     const int64_t j1 = (j0 + per_chunk < m) ? j0 + per_chunk : m;
-    const bool mixed = metric.mixed != 0;
     const double eps = metric.epsilon, b2 = metric.beta * metric.beta;
-    const double scale = mixed ? metric.alpha / metric.mf : 1.0;      // frank_wolfe.py:832-838
-    const double lin = mixed ? (1.0 - metric.alpha) / metric.kf : 0.0;
+    const double scale = MIXED ? metric.alpha / metric.mf : 1.0;      // frank_wolfe.py:832-838
+    const double lin = MIXED ? (1.0 - metric.alpha) / metric.kf : 0.0;
+    double lin0 = 0.0, lin1 = 0.0; // this thread's labels: sum of the constant / of the alpha coefficient
     for (int64_t base = j0; base < j1; base += XC_FW_TILE) {
         const int64_t j = base + threadIdx.x;
-        const int cnt = (int)((j1 - base < XC_FW_TILE) ? j1 - base : XC_FW_TILE);
-        __syncthreads();
+        double N0 = 0.0, dN = 0.0, D0 = 1.0, dD = 0.0;
+        bool smooth = false, rough = false;
         if (j < j1) {
             const double tp = cur[j], fp = cur[m + j], fn = cur[2 * m + j];
             const double dtp = nxt[j] - tp, dfp = nxt[m + j] - fp, dfn = nxt[2 * m + j] - fn;
-            double N0, dN, D0, dD;
             if (BASE == XC_M_PRECISION) {
                 N0 = tp, dN = dtp, D0 = tp + fp + eps, dD = dtp + dfp;
             } else if (BASE == XC_M_RECALL) {
@@ -220,33 +243,88 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_linfrac_kernel(int6
             } else { // XC_M_JACCARD
                 N0 = tp, dN = dtp, D0 = tp + fp + fn + eps, dD = dtp + dfp + dfn;
             }
-            s_c[threadIdx.x][0] = N0 * scale;
-            s_c[threadIdx.x][1] = dN * scale;
-            s_c[threadIdx.x][2] = D0;
-            s_c[threadIdx.x][3] = dD;
-            s_c[threadIdx.x][4] = lin * tp;
-            s_c[threadIdx.x][5] = lin * dtp;
+            N0 *= scale, dN *= scale;
+            if (MIXED) {
+                lin0 += lin * tp;
+                lin1 += lin * dtp;
+            }
+            const double D1 = D0 + dD;
+            const double dlow = fmin(D0, D1), dhigh = fmax(D0, D1);
+            if (dD == 0.0 && D0 > 0.0) {
+                lin0 += N0 / D0;
+                lin1 += dN / D0;
+            } else if (dlow > 0.0 && dhigh <= XC_FW_SMOOTH_RATIO * dlow && fabs(dN) <= XC_FW_SMOOTH_C1 * fabs(dD)) {
+                const double c1 = dN / dD;
+                lin0 += c1;
+                N0 = __builtin_fma(-c1, D0, N0); // c2
+                smooth = true;
+            } else {
+                rough = true;
+            }
+        }
+        const unsigned long long b_smooth = __ballot(smooth), b_rough = __ballot(rough);
+        __syncthreads(); // the previous tile has been read by every thread
+        if (lane == 0) {
+            s_smooth[wave] = __popcll(b_smooth);
+            s_rough[wave] = __popcll(b_rough);
+        }
+        __syncthreads();
+        int n_smooth = 0, n_rough = 0, smooth_before = 0, rough_before = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (w < wave) {
+                smooth_before += s_smooth[w];
+                rough_before += s_rough[w];
+            }
+            n_smooth += s_smooth[w];
+            n_rough += s_rough[w];
+        }
+        if (smooth || rough) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int pos = smooth ? smooth_before + __popcll(b_smooth & below)
+                                   : XC_FW_TILE - 1 - (rough_before + __popcll(b_rough & below));
+            s_c[pos][0] = N0;
+            s_c[pos][1] = dN;
+            s_c[pos][2] = D0;
+            s_c[pos][3] = dD;
         }
         __syncthreads();
 #pragma unroll 2
-        for (int i = 0; i < cnt; ++i) {
-            const double N0 = s_c[i][0], dN = s_c[i][1], D0 = s_c[i][2], dD = s_c[i][3];
-            if (mixed) {
-                const double L0 = s_c[i][4], dL = s_c[i][5];
+        for (int i = 0; i < n_smooth; ++i) {
+            const double c2 = s_c[i][0], cD0 = s_c[i][2], cdD = s_c[i][3];
 #pragma unroll
-                for (int a = 0; a < A; ++a)
-                    sum[a] += fdiv<false>(__builtin_fma(alpha[a], dN, N0), __builtin_fma(alpha[a], dD, D0)) +
-                              __builtin_fma(alpha[a], dL, L0);
-            } else {
-#pragma unroll
-                for (int a = 0; a < A; ++a)
-                    sum[a] += fdiv<false>(__builtin_fma(alpha[a], dN, N0), __builtin_fma(alpha[a], dD, D0));
-            }
+            for (int a = 0; a < A; ++a)
+                sum[a] = __builtin_fma(c2, fw_rcp(__builtin_fma(alpha[a], cdD, cD0)), sum[a]);
         }
+#pragma unroll 2
+        for (int i = XC_FW_TILE - n_rough; i < XC_FW_TILE; ++i) {
+            const double cN0 = s_c[i][0], cdN = s_c[i][1], cD0 = s_c[i][2], cdD = s_c[i][3];
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+                sum[a] += __builtin_fma(alpha[a], cdN, cN0) * fw_rcp(__builtin_fma(alpha[a], cdD, cD0));
+        }
+    }
+    // the per-label sums of the whole chunk, in a fixed order: lanes, then wavefronts
+#pragma unroll
+    for (int off = XC_WAVE / 2; off > 0; off >>= 1) {
+        lin0 += __shfl_xor(lin0, off);
+        lin1 += __shfl_xor(lin1, off);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        s_lin[wave][0] = lin0;
+        s_lin[wave][1] = lin1;
+    }
+    __syncthreads();
+    lin0 = s_lin[0][0], lin1 = s_lin[0][1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        lin0 += s_lin[w][0];
+        lin1 += s_lin[w][1];
     }
 #pragma unroll
     for (int a = 0; a < A; ++a)
-        if (t[a] < n_alpha) partials[(int64_t)blockIdx.y * n_alpha + t[a]] = sum[a];
+        if (t[a] < n_alpha) partials[(int64_t)blockIdx.y * n_alpha + t[a]] = sum[a] + __builtin_fma(alpha[a], lin1, lin0);
 }
 
 } // namespace xc
@@ -293,15 +371,18 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_
         hipLaunchKernelGGL((xc::fw_alpha_curve_kernel<false, B>), dim3(gx, chunks), dim3(XC_FW_TILE), 0, st, m, cur, \
                            nxt, *metric_host, n_alpha, alphas, per_chunk, partials);                               \
         break
+#define XC_FW_SCAN_LINFRAC_AM(B, A, M)                                                                              \
+    hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B, A, M>), dim3((gx + A - 1) / A, chunks),                 \
+                       dim3(XC_FW_TILE), 0, st, m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials)
 #define XC_FW_SCAN_LINFRAC(B)                                                                                      \
     case B:                                                                                                        \
-        if (n_alpha >= 4 * XC_FW_TILE)                                                                             \
-            hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B, 4>), dim3((gx + 3) / 4, chunks),              \
-                               dim3(XC_FW_TILE), 0, st, m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk,     \
-                               partials);                                                                          \
-        else                                                                                                       \
-            hipLaunchKernelGGL((xc::fw_alpha_curve_linfrac_kernel<B, 1>), dim3(gx, chunks), dim3(XC_FW_TILE), 0,   \
-                               st, m, cur, nxt, *metric_host, n_alpha, alphas, per_chunk, partials);               \
+        if (n_alpha >= 4 * XC_FW_TILE) {                                                                           \
+            if (metric_host->mixed) XC_FW_SCAN_LINFRAC_AM(B, 4, true);                                             \
+            else XC_FW_SCAN_LINFRAC_AM(B, 4, false);                                                               \
+        } else {                                                                                                   \
+            if (metric_host->mixed) XC_FW_SCAN_LINFRAC_AM(B, 1, true);                                             \
+            else XC_FW_SCAN_LINFRAC_AM(B, 1, false);                                                               \
+        }                                                                                                          \
         break
         switch (metric_host->base) {
             XC_FW_SCAN(XC_M_PRECISION_AT_K);
@@ -316,6 +397,7 @@ int xc_fw_alpha_curve(int64_t m, const double *cur, const double *nxt, const xc_
             XC_FW_SCAN(XC_M_RECALL_PRECISION_MIX);
         }
 #undef XC_FW_SCAN_LINFRAC
+#undef XC_FW_SCAN_LINFRAC_AM
 #undef XC_FW_SCAN
     }
     XC_CHECK_LAUNCH("fw_alpha_curve_kernel");
