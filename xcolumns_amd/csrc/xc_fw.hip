@@ -188,7 +188,7 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
 //           applied to every step size at the end; nothing per evaluation;
 //   smooth  psi = c1 + c2 / d(alpha) with c1 = dN/dD, c2 = N0 - c1 D0 (n - c1 d does not depend on alpha):
 //           c1 joins the per-label sums, an evaluation is d = fma(alpha, dD, D0), its reciprocal (v_rcp_f64 +
-//           two Newton steps) and one fma -- 7 float64 instructions instead of 9.  Taken when |c1| <= 64 and
+//           one cubic step) and one fma -- 6 float64 instructions instead of 9.  Taken when |c1| <= 64 and
 //           the two end-point denominators are within 1024x of each other, which bounds the cancellation in
 //           c1 + c2 r to ~1e-11 absolute per label (the label sums are O(m));
 //   rough   everything else (denominators that start or end near epsilon, 0/0): numerator * reciprocal.
@@ -196,10 +196,12 @@ __global__ __launch_bounds__(XC_FW_TILE) void fw_alpha_curve_kernel(int64_t m, c
 // labels are staged from the front of the tile, rough ones from the back: two branch-free loops.
 #define XC_FW_SMOOTH_C1 64.0
 #define XC_FW_SMOOTH_RATIO 1024.0
+// v_rcp_f64 is good to 2^-24.4 on gfx950 (tools/rcp_probe.hip); one cubic step r (1 + e + e^2), e = 1 - d r,
+// takes that to 2^-53 in three fmas (two Newton steps need four)
 __device__ __forceinline__ double fw_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 
 template <int BASE, int A, bool MIXED>
