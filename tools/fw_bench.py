@@ -3,6 +3,7 @@
     python tools/fw_bench.py [n] [m] [iters]
 
 Synthetic y_proba as in bench.py (r = 50 entries per row, float32), y_true drawn from it."""
+import os
 import sys
 import time
 
@@ -52,6 +53,10 @@ for it in range(iters):
     stats_i = timed("predict+confusion", lambda: eng.confusion_of(a, b), acc)
     timed("utility", lambda: eng.utility(stats_i), acc)
     alpha = timed("alpha search (10^4 points)", lambda: eng.best_alpha(stats, stats_i, "uniform", 1e-3, 1e-4), acc)
+    if os.environ.get("XC_FW_COUNT_DISTINCT"):  # how many distinct (cur, nxt) label tuples does the scan see
+        both = torch.cat([stats[:3], stats_i[:3]]).t().contiguous()
+        moved = int((stats[:3] != stats_i[:3]).any(dim=0).sum())
+        print(f"  labels {m}, moved by the step {moved}, distinct (cur, nxt) tuples {torch.unique(both, dim=0).shape[0]}", flush=True)
     stats = (1 - alpha) * stats + alpha * stats_i
     print(f"iter {it}: alpha {alpha} utility {eng.utility(stats):.6f}", flush=True)
 for kx, v in acc.items():
