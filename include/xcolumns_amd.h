@@ -78,11 +78,14 @@ typedef struct xc_metric {
  *                          so far (constant during a non-greedy sweep);
  *   s_entry float64[nnz]   colsum expanded per stored entry of y_proba, so it
  *                          streams in with the row instead of being gathered.
- *   packed  16 B x nnz     optional (float32 scores, m <= 2^25): {col | hot << 25 |
- *                          sel << 31, eta, s} per stored entry -- indices, data, sel and
- *                          s_entry (and the label's hot slot, 0 = none) interleaved,
- *                          so a candidate streams in as ONE 16-byte lane load
- *                          (xc_bca_pack_rows; the sweep keeps its sel bits current).
+ *   packed  12 B x nnz     optional (float32 scores, m <= 2^25): {col | hot << 25 |
+ *                          sel << 31, eta, (float) s} per stored entry -- indices, data,
+ *                          sel and s_entry (and the label's hot slot, 0 = none)
+ *                          interleaved, so a candidate streams in as ONE 12-byte lane
+ *                          load (xc_bca_pack_rows; the sweep keeps its sel bits
+ *                          current).  Read by the concurrent sweeps only: s is rounded
+ *                          to float32 like the shadow records; the exact sequential
+ *                          sweep (n_waves == 1) reads the separate float64 streams.
  *   shadow  float32[m][2]  optional rounded copy of tpfp (8-byte records): what the
  *                          CONCURRENT sweep gathers, so twice as many labels stay in
  *                          an XCD's 4 MiB L2; written by xc_bca_commit_utility, kept
@@ -159,8 +162,8 @@ int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_p
 
 /* ---- block coordinate ascent, CSR ------------------------------------- */
 
-/* packed[p] <- {indices[p] | hot_slot[indices[p]] << 25 | sel[p] << 31, data[p], s_entry[p]}
- * for float32 scores (column ids < 2^25).  hot_slot: optional uint8[m], 1..63 for the
+/* packed[p] <- {indices[p] | hot_slot[indices[p]] << 25 | sel[p] << 31, data[p], (float) s_entry[p]}
+ * (three 32-bit words per entry) for float32 scores (column ids < 2^25).  hot_slot: optional uint8[m], 1..63 for the
  * labels whose deltas a sweeping wave batches (see xc_bca_sweep_csr `hot_labels`), 0 else. */
 int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data,
                      const uint8_t *sel, const double *s_entry, const uint8_t *hot_slot,
@@ -233,8 +236,10 @@ int xc_utility_finish_host(const double *partials, double *out_host,
  *   shadow       optional float32 copy of tpfp (see above); NULL = gather tpfp
  *   s_entry      colsum per stored entry (xc_bca_expand_colsum); may be NULL when
  *                greedy (colsum is then gathered and grows during the sweep)
- *   packed       optional packed row stream (float32 scores, non-greedy); NULL = read
- *                indices / data / sel / s_entry separately
+ *   packed       optional packed row stream (float32 scores, non-greedy, n_waves > 1); NULL = read
+ *                indices / data / sel / s_entry separately.  A sweep that does not read it
+ *                (greedy, n_waves == 1) leaves its sel bits stale: call xc_bca_pack_rows again
+ *                before the next sweep that does
  *   hot_labels   optional int32[64] (with packed, shadow and acc): label id of hot slot
  *                h = 1..63 (-1 = unused; entry 0 unused).  A wave sums its deltas to these
  *                labels in LDS and publishes them every few rows as one atomic per label

@@ -161,9 +161,9 @@ class BcaCsrEngine:
         self.shadow = torch.zeros((m, 2), dtype=torch.float32, device=dev) if use_shadow else None
         self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
         self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
-        # float32 scores: indices / data / sel / s_entry interleaved in 16-byte entries, so a
-        # candidate streams in as one 16-byte lane load (XCOLUMNS_BCA_PACKED=0 disables)
-        self.packed = (torch.empty((max(1, csr.nnz), 4), dtype=torch.int32, device=dev)
+        # float32 scores: indices / data / sel / (float) s_entry interleaved in 12-byte entries, so a
+        # candidate streams in as one 12-byte lane load (XCOLUMNS_BCA_PACKED=0 disables)
+        self.packed = (torch.empty((max(1, csr.nnz), 3), dtype=torch.int32, device=dev)
                        if csr.data.dtype == torch.float32 and m <= (1 << 25)
                        and os.environ.get("XCOLUMNS_BCA_PACKED", "1") != "0" else None)
         self._pack_dirty = True
@@ -319,14 +319,16 @@ class BcaCsrEngine:
         full = n_order >= c.n
         if not full:
             self.changed.zero_()
-        use_packed = self.packed is not None and not greedy
+        # the packed stream serves the concurrent sweeps (its s is float32); greedy and one-wavefront (exact)
+        # sweeps read the separate streams and leave the packed copy's membership bits stale
+        use_packed = self.packed is not None and not greedy and int(n_waves) > 1
         if use_packed and self._pack_dirty:
             self._repack()
         _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(order), int(n_order), D.ptr(self.orphans),
                   int(bool(greedy)), int(n_waves), int(full), int(use_packed),
                   None if full else D.ptr(self.changed), D.stream())
-        if greedy:
-            self._pack_dirty = True  # the greedy sweep rewrites sel without touching the packed copy
+        if not use_packed:
+            self._pack_dirty = True  # sel was rewritten without touching the packed copy
         self._acc_filled = full
         self._partial_sweep = not full
         # every row was visited: no orphan is left in any prediction

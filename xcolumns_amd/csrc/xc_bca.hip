@@ -39,6 +39,10 @@
 namespace xc {
 
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+// one packed row entry: three dwords, dword-aligned (global_load_dwordx3)
+struct __attribute__((packed, aligned(4))) pack3_t {
+    unsigned x, y, z;
+};
 
 template <typename T>
 struct SweepParams {
@@ -57,8 +61,9 @@ struct SweepParams {
                             // concurrent sweep (8-byte records: twice the labels per L2 byte)
     double *colsum;         // [m] s = tp + fn
     const double *s_entry;  // [nnz] colsum expanded per stored entry (NULL in the greedy sweep)
-    uint4_t *packed;        // optional [nnz] 16-byte entries {col | sel << 31, eta (f32), s (f64)}: the
-                            // row streams interleaved so a candidate is ONE 16-byte lane load
+    pack3_t *packed;        // optional [nnz] 12-byte entries {col | hot << 25 | sel << 31, eta (f32), s (f32)}:
+                            // the row streams interleaved so a candidate is ONE 12-byte lane load
+                            // (concurrent sweeps only: the exact mode reads the float64 s_entry)
     const int32_t *hot_labels; // optional [64] (with packed): label id of hot slot h = 1..63, -1 = unused
     double *acc;            // optional [2m + 1]: from-scratch {tp, fp} of the NEW prediction, [2m] += changed rows
     int64_t m;
@@ -132,13 +137,16 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
         // read-once streams: non-temporal, so they do not evict the {tp, fp} records
         // (the gather table) from the XCD's L2
         if (PACKED) {
-            // one 16-byte load per lane = 1 KiB per wave instruction, the widest shape
-            const uint4_t w = __builtin_nontemporal_load(P.packed + s + pc);
-            d.idx[c] = (int)(w.x & XC_PACK_COL_MASK);
-            d.hot[c] = (uint8_t)((w.x >> XC_PACK_HOT_SHIFT) & XC_PACK_HOT_MASK);
-            d.sel[c] = (uint8_t)(w.x >> 31);
-            d.eta[c] = (T)__uint_as_float(w.y);
-            d.sc[c] = __longlong_as_double((long long)(((unsigned long long)w.w << 32) | w.z));
+            // one 12-byte load per lane = 768 contiguous bytes per wave instruction
+            const pack3_t *e = P.packed + s + pc;
+            const unsigned wx = __builtin_nontemporal_load(&e->x);
+            const unsigned wy = __builtin_nontemporal_load(&e->y);
+            const unsigned wz = __builtin_nontemporal_load(&e->z);
+            d.idx[c] = (int)(wx & XC_PACK_COL_MASK);
+            d.hot[c] = (uint8_t)((wx >> XC_PACK_HOT_SHIFT) & XC_PACK_HOT_MASK);
+            d.sel[c] = (uint8_t)(wx >> 31);
+            d.eta[c] = (T)__uint_as_float(wy);
+            d.sc[c] = (double)__uint_as_float(wz);
         } else {
             d.idx[c] = __builtin_nontemporal_load(P.indices + s + pc);
             d.eta[c] = __builtin_nontemporal_load(P.data + s + pc);
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                 if (lane + XC_WAVE * c < r && in_new[c] != (cur.sel[c] != 0)) {
                     P.sel[s0 + lane + XC_WAVE * c] = in_new[c] ? 1 : 0;
                     if (PACKED)
-                        reinterpret_cast<unsigned *>(P.packed + s0 + lane + XC_WAVE * c)[0] =
+                        P.packed[s0 + lane + XC_WAVE * c].x =
                             (unsigned)cur.idx[c] | ((unsigned)cur.hot[c] << XC_PACK_HOT_SHIFT) |
                             (in_new[c] ? 0x80000000u : 0u);
                 }
@@ -667,20 +675,18 @@ __global__ __launch_bounds__(XC_BLOCK) void expand_colsum_kernel(int64_t nnz, co
         s_entry[t] = colsum[indices[t]];
 }
 
-// packed[p] = {col | sel << 31, eta, s}: the four row streams of a float32 matrix interleaved
+// packed[p] = {col | hot << 25 | sel << 31, eta, (float)s}: the four row streams of a float32 matrix interleaved
 __global__ __launch_bounds__(XC_BLOCK) void pack_rows_kernel(int64_t nnz, const int32_t *indices, const float *data,
                                                              const uint8_t *sel, const double *s_entry,
-                                                             const uint8_t *hot_slot, uint4_t *packed) {
+                                                             const uint8_t *hot_slot, pack3_t *packed) {
     const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
     for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride) {
-        const unsigned long long sb = (unsigned long long)__double_as_longlong(s_entry[t]);
-        uint4_t w;
+        pack3_t w;
         const unsigned col = (unsigned)indices[t];
         w.x = col | ((hot_slot ? (unsigned)hot_slot[col] & XC_PACK_HOT_MASK : 0u) << XC_PACK_HOT_SHIFT) |
               (sel[t] ? 0x80000000u : 0u);
         w.y = __float_as_uint(data[t]);
-        w.z = (unsigned)sb;
-        w.w = (unsigned)(sb >> 32);
+        w.z = __float_as_uint((float)s_entry[t]);
         packed[t] = w;
     }
 }
@@ -920,7 +926,8 @@ static void launch_sweep_mode(const SweepParams<T> &P, int ch, hipStream_t st) {
 // The float32 shadow is read by the concurrent, non-greedy sweep only; the packed row
 // stream exists for float32 scores and non-greedy sweeps.
 static void launch_sweep(const SweepParams<float> &P, int ch, hipStream_t st) {
-    if (P.packed && !P.greedy) launch_sweep_mode<float, true>(P, ch, st);
+    const bool exact = P.n_waves == 1 && !P.ctrl; // the packed stream carries s in float32
+    if (P.packed && !P.greedy && !exact) launch_sweep_mode<float, true>(P, ch, st);
     else launch_sweep_mode<float, false>(P, ch, st);
 }
 
@@ -993,7 +1000,7 @@ int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data, con
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_pack_rows: bad argument");
     if (nnz == 0) return XC_OK;
     hipLaunchKernelGGL(xc::pack_rows_kernel, dim3(xc::grid_for(nnz)), dim3(XC_BLOCK), 0, xc::as_stream(stream), nnz, indices,
-                       data, sel, s_entry, hot_slot, static_cast<xc::uint4_t *>(packed));
+                       data, sel, s_entry, hot_slot, static_cast<xc::pack3_t *>(packed));
     XC_CHECK_LAUNCH("pack_rows_kernel");
     return XC_OK;
 }
@@ -1098,7 +1105,7 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
                                  static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
-                                 static_cast<xc::uint4_t *>(packed), packed ? hot_labels : nullptr, acc, m,
+                                 static_cast<xc::pack3_t *>(packed), packed ? hot_labels : nullptr, acc, m,
                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
