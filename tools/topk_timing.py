@@ -3,7 +3,10 @@
 import sys
 import torch
 sys.path.insert(0, ".")
-from xcolumns_amd import _device as D
+import os
+from xcolumns_amd import _device as D, _lib
+if os.environ.get("XC_LIB"):
+    _lib.LIB_PATH = os.environ["XC_LIB"]
 from xcolumns_amd.synthetic import WORKLOADS, make_csr
 from xcolumns_amd.weighted_prediction import topk_csr_device
 

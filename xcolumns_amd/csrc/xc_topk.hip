@@ -255,26 +255,54 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
             sel[c] = false;
         }
         const int want = r < k ? r : k; // :465-466: a row of at most k entries keeps them all
+        // Selection = a tournament of the 16 lanes' sorted lists (the kernel is bound by these instructions, not
+        // by HBM: 82 us without them at 1M x 50).  Each lane first sorts its four keys in descending order with a
+        // stable network of adjacent exchanges (equal keys keep their position order; q* = entry index of a
+        // slot); a round is then ONE 16-lane DPP max over the list heads, a ballot that names the first lane
+        // holding it (ties go to the lower column) and a pop in that lane.
+        unsigned k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3];
+        unsigned q0 = 0, q1 = 1, q2 = 2, q3 = 3;
+#define XC_Q4_CSWAP(ka, kb, qa, qb)                                                                                \
+    {                                                                                                              \
+        const bool sw = kb > ka;                                                                                   \
+        const unsigned tk = sw ? kb : ka, tq = sw ? qb : qa;                                                       \
+        kb = sw ? ka : kb;                                                                                         \
+        qb = sw ? qa : qb;                                                                                         \
+        ka = tk;                                                                                                   \
+        qa = tq;                                                                                                   \
+    }
+        XC_Q4_CSWAP(k0, k1, q0, q1);
+        XC_Q4_CSWAP(k2, k3, q2, q3);
+        XC_Q4_CSWAP(k1, k2, q1, q2);
+        XC_Q4_CSWAP(k0, k1, q0, q1);
+        XC_Q4_CSWAP(k2, k3, q2, q3);
+        XC_Q4_CSWAP(k1, k2, q1, q2);
+#undef XC_Q4_CSWAP
+        unsigned selmask = 0u;
+#ifdef XC_EXP_TOPK_NOSELECT /* diagnostic build (tools/build_exp.sh): memory-only floor, wrong results */
+        const int rounds = 0;
+        selmask = l16 < want ? 1u : 0u;
+#else
         // the four rows of a wave may need different numbers of rounds: run the maximum
         const int rounds = (int)wave_umax32((unsigned)want);
+#endif
+        const unsigned my_bit = 1u << l16;
+        // (no `round < want` test: a row with fewer than k entries runs out of non-zero heads by itself)
         for (int round = 0; round < rounds; ++round) {
-            // best remaining entry of this lane: highest key, lowest position on ties
-            unsigned lk = 0, lp = 255;
-#pragma unroll
-            for (int c = 3; c >= 0; --c)
-                if (!sel[c] && key[c] != 0u && key[c] >= lk) {
-                    lk = key[c];
-                    lp = (unsigned)(4 * l16 + c);
-                }
-            const unsigned M = row16_umax32(lk);
-            // the winner is the first holder of M in position order (ties go to the lower column)
-            const unsigned Pw = row16_umin32((lk == M && M != 0u) ? lp : 255u);
-            if (round < want && (Pw >> 2) == (unsigned)l16 && Pw != 255u) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if ((int)(Pw & 3u) == c) sel[c] = true;
-            }
+            const unsigned M = row16_umax32(k0);
+            const unsigned holders = seg16(__builtin_amdgcn_ballot_w64(k0 == M && k0 != 0u));
+            const bool win = (holders & (0u - holders)) == my_bit; // lowest holder of this DPP row
+            selmask |= win ? (1u << q0) : 0u;
+            k0 = win ? k1 : k0;
+            k1 = win ? k2 : k1;
+            k2 = win ? k3 : k2;
+            k3 = win ? 0u : k3;
+            q0 = win ? q1 : q0;
+            q1 = win ? q2 : q1;
+            q2 = win ? q3 : q2;
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sel[c] = (selmask >> c) & 1u;
 
         // ascending-column emission inside the DPP row: positions are lane-major
         int32_t *o_idx = P.out_indices + row * k;

@@ -35,6 +35,13 @@ def topk_csr_device(csr: D.DeviceCSR, k: int, a: Optional[torch.Tensor] = None,
     out_idx = torch.empty(n * k, dtype=torch.int32, device=dev)
     out_dat = torch.empty(n * k, dtype=csr.data.dtype, device=dev)
     out_eta = torch.empty(n * k, dtype=csr.data.dtype, device=dev) if want_eta else None
+    if a is not None and b is not None:
+        # both weights: interleave them (an O(m) copy) so a candidate costs one gather, not two -- same gains
+        ab = torch.stack([a, b], dim=1).contiguous()
+        _lib.call("xc_topk_csr_ab", n, D.ptr(csr.indptr), D.ptr(csr.indices), D.ptr(csr.data), csr.code,
+                  int(csr.max_row_nnz), int(k), D.ptr(ab), int(bool(keep_scores)),
+                  D.ptr(out_idx), D.ptr(out_dat), D.ptr(out_eta), D.ptr(out_sel), D.stream())
+        return out_idx, out_dat, out_eta
     _lib.call("xc_topk_csr", n, D.ptr(csr.indptr), D.ptr(csr.indices), D.ptr(csr.data), csr.code,
               int(csr.max_row_nnz), int(k), D.ptr(a), D.ptr(b), int(bool(keep_scores)),
               D.ptr(out_idx), D.ptr(out_dat), D.ptr(out_eta), D.ptr(out_sel), D.stream())
