@@ -9,7 +9,7 @@ from xcolumns_amd import _device as D
 from xcolumns_amd.block_coordinate import BcaCsrEngine
 from xcolumns_amd.metrics import MetricSpec
 from xcolumns_amd.synthetic import make_csr
-n, m = 100_000, 30_000
+n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100_000, 30_000)
 Y = make_csr(n, m, 50, seed=20240001, zipf=True)
 dev = D.require_gpu(); csr = D.DeviceCSR.from_scipy(Y, dev); spec = MetricSpec(base=_lib.XC_M_FBETA)
 rng = np.random.default_rng(13); order = np.arange(n); rng.shuffle(order)
