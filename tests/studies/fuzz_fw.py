@@ -52,6 +52,13 @@ def one(seed):
     if not np.isfinite(A).all() or not np.isfinite(mo["utilities"]).all():
         return True, "skipped (non-finite classifier or utility in the oracle too)"
     tol = 1e-12 if dtype == np.float64 else 2e-6
+    if os.environ.get("XC_FUZZ_DETAIL"):
+        print(desc)
+        print(" iters", mg["iters"], mo["iters"])
+        print(" alphas gpu   ", list(mg["alphas"]))
+        print(" alphas oracle", list(mo["alphas"]))
+        print(" utilities gpu   ", list(mg["utilities"]))
+        print(" utilities oracle", list(mo["utilities"]))
     ok = mg["iters"] == mo["iters"] and np.array_equal(np.asarray(mg["alphas"], dtype=np.float64), np.asarray(mo["alphas"], dtype=np.float64))
     ok = ok and np.allclose(mg["utilities"], mo["utilities"], rtol=tol, atol=tol) and np.array_equal(clf.p, P)
     scale = float(np.abs(A).max()) or 1.0
