@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- BCA macro-F1 sweeps on synthetic sparse score matrices.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--zipf]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--scaling weak|strong] [--zipf]
 
-One "step" = one BCA sweep (block_coordinate.py:448-463 of the reference) over
-the rank's rows PLUS the sweep-boundary work the reference does every
-iteration: the from-scratch recompute of the expected confusion statistics
-(:465-467; one all-reduce when N > 1), the utility (:469-476) and its transfer
-to the host for the stopping rule.  Inputs (CSR y_proba, the initial top-k
-prediction, and the visiting orders of all W+K sweeps, generated with the
-reference's own np.random.default_rng stream) are resident in HBM before the
-timed region.  Weak scaling: every rank holds the workload's n rows
-(global n = N x n); value = N * n * K / max-over-ranks time.
+One "step" = one BCA sweep (block_coordinate.py:448-463 of the reference) over the rank's rows PLUS
+the sweep-boundary work the reference does every iteration: the from-scratch recompute of the
+expected confusion statistics (:465-467; one all-reduce when N > 1), the utility (:469-476) and its
+transfer to the host for the stopping rule.  Inputs (CSR y_proba, the initial top-k prediction and
+the visiting orders of all sweeps -- the reference's np.random.default_rng stream) are resident in
+HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for every field).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD (it
+never touches the GPU itself and never re-executes), passes rank 0's JSON line on and exits with
+the child's code.  Under torch.distributed.run (the driver's own launch) it is a worker.
+
+Scaling: "weak" (default; every rank holds the workload's n rows, global n = N x n) and "strong"
+(`--scaling strong`: the workload's n rows split over the N ranks -- BASELINE configs[3]'s
+"instance-sharded").  N = 1 is the same run in both.  For N > 1 the weak line also carries a
+`strong_scaling` object measured in the same process, so one driver run yields both curves.
+
+Prints ONE JSON line on rank 0 (DESIGN.md "measurement" explains every field).
 """
 from __future__ import annotations
 
@@ -21,6 +28,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +42,8 @@ if ROOT not in sys.path:
 R_NNZ = 50   # stored entries per row (primary)
 K = 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MATRIX_SEED = 20240001
+ORDER_SEED = 13
 
 
 def algorithmic_bytes_per_row_step(r: int, k: int) -> int:
@@ -49,10 +60,65 @@ def algorithmic_bytes_per_row_sweep(r: int, k: int) -> int:
     return 8 + 40 * r + 12 * k
 
 
-def cpu_baseline(Y, k, seed, budget_s=12.0):
-    """The oracle (oracle/, a C restatement of the reference's sequential sweep) timed
-    on ONE host core on a bounded sample of the same workload: whole sweeps over
-    the first rows of the same matrix until ~budget_s of CPU work."""
+# ---------------------------------------------------------------------------
+# parent: start the N ranks as children
+# ---------------------------------------------------------------------------
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(n_gpus: int) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: run the N ranks as a child process
+    tree and relay rank 0's JSON line.  Nothing here imports torch or touches the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith('{"metric"'):
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return rc
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline legs (rank 0, N = 1): the oracle timed on the host cores
+# ---------------------------------------------------------------------------
+
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(Y, k, seed, budget_s=10.0):
+    """The oracle (oracle/, a C restatement of the reference's kernels) on the host cores, on a bounded
+    sample of the same workload.  (i) The BCA sweep on ONE core -- the reference's row loop is serial
+    (block_coordinate.py:448): whole sweeps over the first rows of the same matrix until ~budget_s.
+    (ii) The row-independent passes -- top-k and the confusion recompute -- with T = 1, 8 and all host
+    cores over rows, the reference under XCOLUMNS_NUMBA_PARALLEL=1 / NUMBA_NUM_THREADS=8
+    (experiments/numba_perf_tests.sh:5-6)."""
     from oracle import ref as oracle_ref
 
     n, m = Y.shape
@@ -60,13 +126,28 @@ def cpu_baseline(Y, k, seed, budget_s=12.0):
     Ys = Y[:n_s]
     metric = oracle_ref.make_metric(oracle_ref.FBETA, k=float(k), m=float(m))
     sweeps, t_total = 0, 0.0
-    it = 2
     while t_total < budget_s and sweeps < 64:
         t0 = time.perf_counter()
-        _, meta = oracle_ref.predict_using_bc_with_0approx(Ys, metric, k, skip_tn=True, seed=seed, max_iters=it,
+        _, meta = oracle_ref.predict_using_bc_with_0approx(Ys, metric, k, skip_tn=True, seed=seed, max_iters=2,
                                                             tolerance=-1.0)
         t_total += time.perf_counter() - t0
         sweeps += meta["iters"]
+    host_cores = os.cpu_count() or 1
+    try:
+        host_cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    legs = {"topk_rows_per_s": {}, "confusion_rows_per_s": {}}
+    n_t = min(n, 1_000_000)
+    Yt = Y[:n_t]
+    pred = None
+    for t in sorted({1, min(8, host_cores), host_cores}):
+        t0 = time.perf_counter()
+        pred = oracle_ref.predict_top_k_threads(Yt, k, t)
+        legs["topk_rows_per_s"][f"T={t}"] = n_t / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        oracle_ref.calculate_confusion_matrix_threads(Yt, pred, t)
+        legs["confusion_rows_per_s"][f"T={t}"] = n_t / (time.perf_counter() - t0)
     return {
         "value": n_s * sweeps / t_total,
         "unit": "rows/s",
@@ -74,7 +155,444 @@ def cpu_baseline(Y, k, seed, budget_s=12.0):
         "kind": "port",
         "sample": f"{sweeps} sequential sweeps over the first {n_s} rows of the same matrix "
                   f"(incl. top-k init and per-sweep confusion recompute), {t_total:.1f} s, 1 thread",
+        "cpu_model": _cpu_model(),
+        "host_cores": host_cores,
+        "row_parallel_legs": dict(legs, sample=f"one pass over the first {n_t} rows, OpenMP threads over rows "
+                                                "(the reference's prange loops); top-k k=5, confusion of that prediction"),
     }
+
+
+# ---------------------------------------------------------------------------
+# worker
+# ---------------------------------------------------------------------------
+
+class Timer:
+    """K timed sweeps of one engine, repeated; everything the JSON line needs from them."""
+
+    def __init__(self, eng, policy, orders, n_local, n_u, m, comm, world, dev):
+        self.eng, self.policy, self.orders = eng, policy, orders
+        self.n, self.n_u, self.m, self.comm, self.world, self.dev = n_local, n_u, m, comm, world, dev
+
+    def _barrier(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, first, last, old_sum, events=None, waves_used=None, host_t=None):
+        """Sweeps first..last-1 exactly as block_coordinate.run_bca_sweeps drives them: the stopping rule
+        and the wavefront policy are evaluated on the GPU at every boundary, the host enqueues sweep
+        j + 1 before it reads the result of sweep j."""
+        from xcolumns_amd import _lib
+        eng, policy, orders, n, n_u, m = self.eng, self.policy, self.orders, self.n, self.n_u, self.m
+        out = []
+        if first >= last:
+            return out
+        pipelined = eng.can_pipeline(n) and not policy.sequential
+        NEVER = -1e300  # tolerance: the stopping rule never fires, every run does exactly K sweeps
+
+        def attach(s):
+            if events is not None:
+                e0, e1 = events[s - first]
+                _lib.call("xc_bca_time_next_sweep", e0, e1)   # HIP events attached to the sweep dispatch itself
+
+        if not pipelined:   # bca_waves = 1 (--waves 1): the host-paced exact loop
+            changed = None
+            for s in range(first, last):
+                attach(s)
+                w = policy.next(changed)
+                eng.sweep(orders[s], n, w, greedy=False)
+                out.append(eng.recompute_utility_sum(n_u))
+                changed = eng.rows_changed()
+                if waves_used is not None:
+                    waves_used.append(w)
+            return out
+        eng.pipeline_begin(old_sum, NEVER, float(m), True, policy, policy.next(None))
+
+        def collect(j):
+            t = time.perf_counter()
+            total, changed, waves, flag = eng.pipeline_result(j)
+            if host_t is not None:
+                host_t["wait_result"] += time.perf_counter() - t
+            if waves_used is not None:
+                waves_used.append(waves)
+            assert flag == 0, flag
+            out.append(total)
+
+        for s in range(first, last):
+            t = time.perf_counter()
+            attach(s)
+            eng.pipeline_step(orders[s], s, n_u)
+            if host_t is not None:
+                host_t["enqueue"] += time.perf_counter() - t
+            if s > first:
+                collect(s - 1)
+        collect(last - 1)
+        return out
+
+    def measure(self, warmup, steps, repeats):
+        """`warmup` untimed sweeps, then `repeats` times: back to the top-k prediction (untimed), barrier,
+        EXACTLY `steps` sweeps (sweeps 1..K of a fresh run, the expensive early ones included), barrier."""
+        import torch
+        import torch.distributed as dist
+        from xcolumns_amd import _lib
+        eng, n_u, m = self.eng, self.n_u, self.m
+        eng.init_top()
+        eng.reset_state(greedy=False)
+        u0_sum = eng.recompute_utility_sum(n_u)
+        self.run(0, warmup, u0_sum)
+        no_events = os.environ.get("XC_BENCH_NO_EVENTS") == "1"
+        elapsed, kernel_ms, utilities, waves = [], [], None, None
+        host_t = {"enqueue": 0.0, "wait_result": 0.0}
+        ar_ms = []
+        for rep in range(repeats):
+            events = None
+            if not no_events:
+                events = []
+                for _ in range(steps):
+                    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+                    _lib.call("xc_event_create", ctypes.byref(e0))
+                    _lib.call("xc_event_create", ctypes.byref(e1))
+                    events.append((e0, e1))
+            eng.init_top()
+            u0_sum = eng.recompute_utility_sum(n_u)
+            if self.comm is not None:
+                self.comm.start_timing()
+            w_used = []
+            self._barrier()
+            t0 = time.perf_counter()
+            sums = self.run(warmup, warmup + steps, u0_sum, events, w_used, host_t)
+            self._barrier()
+            dt = time.perf_counter() - t0
+            if self.world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            elapsed.append(dt)
+            if self.comm is not None:
+                ar_ms.append(self.comm.stop_timing())
+            if events is not None:
+                row = []
+                for a, b in events:
+                    ms = ctypes.c_float(0.0)
+                    _lib.call("xc_event_elapsed_ms", a, b, ctypes.byref(ms))
+                    row.append(ms.value)
+                    _lib.call("xc_event_destroy", a)
+                    _lib.call("xc_event_destroy", b)
+                kernel_ms.append(row)
+            utilities = [u / m for u in sums]
+            waves = w_used
+        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "utilities": utilities, "waves": waves,
+                "u_top_k": u0_sum / m, "host_t": {k: v / (repeats * steps) * 1e3 for k, v in host_t.items()},
+                "allreduce_ms": ar_ms}
+
+
+def _median(xs):
+    return float(np.median(np.asarray(xs, dtype=np.float64)))
+
+
+def roofline_of(kernel_ms, n_rows, by_sweep=True):
+    """Fractions of the HBM roofline from per-launch kernel times [repeat][sweep] (ms)."""
+    b_step, b_sweep = algorithmic_bytes_per_row_step(R_NNZ, K), algorithmic_bytes_per_row_sweep(R_NNZ, K)
+    a = np.asarray(kernel_ms, dtype=np.float64)
+    avg_s = float(a.mean()) / 1e3
+    achieved = b_sweep * n_rows / avg_s / 1e9
+    out = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "avg_kernel_ms": avg_s * 1e3,
+           "frac_step_pass_only": b_step * n_rows / avg_s / 1e9 / HBM_PEAK_GBS}
+    if by_sweep:
+        med = np.median(a, axis=0)
+        out["kernel_ms_by_sweep"] = [round(float(x), 4) for x in med]
+        out["frac_by_sweep"] = [round(float(b_sweep * n_rows / (x / 1e3) / 1e9 / HBM_PEAK_GBS), 4) for x in med]
+    return out
+
+
+def worker(args):
+    import torch
+    import torch.distributed as dist
+
+    from xcolumns_amd import _device as D
+    from xcolumns_amd import _lib
+    from xcolumns_amd.block_coordinate import BcaCsrEngine, WavePolicy
+    from xcolumns_amd.distributed import TorchComm, local_order, shard_bounds
+    from xcolumns_amd.metrics import MetricSpec
+    from xcolumns_amd.synthetic import WORKLOADS, make_csr_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or without it (bench.py starts the ranks itself)")
+    # XC_BENCH_BACKEND=gloo + XC_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow with several ranks on
+    # ONE GPU (RCCL refuses duplicate devices); never used for numbers.
+    one_device = os.environ.get("XC_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one_device else local_rank)
+    dev = D.require_gpu()
+    comm, backend = None, None
+    if world > 1 or os.environ.get("XC_BENCH_FORCE_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = os.environ.get("XC_BENCH_BACKEND", "nccl")
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        comm = TorchComm()
+        backend = dist.get_backend()
+
+    n, m = WORKLOADS[args.workload]
+    spec = MetricSpec(base=_lib.XC_M_FBETA)  # macro-F1: binary_f1_score_on_conf_matrix, eps 1e-9
+    total_sweeps = args.warmup + args.steps
+    extras = not args.no_extras and world == 1
+
+    def build(scaling, zipf, use_shadow=None, packed=True):
+        """(engine, policy, orders, local rows, global rows, host matrix) of this rank for one mode."""
+        n_global = n * world if scaling == "weak" else n
+        lo, hi = shard_bounds(n_global, world, rank)
+        if scaling == "weak":
+            # rank r holds the whole n-row workload matrix, generated from its own seeds
+            Y = make_csr_rows(n, m, 0, n, R_NNZ, seed=MATRIX_SEED + 8 * rank, zipf=zipf, k=K)
+        else:
+            Y = make_csr_rows(n, m, lo, hi, R_NNZ, seed=MATRIX_SEED, zipf=zipf, k=K)
+        csr = D.DeviceCSR.from_scipy(Y, dev)
+        if not packed:
+            os.environ["XCOLUMNS_BCA_PACKED"] = "0"
+        try:
+            eng = BcaCsrEngine(csr, K, spec, spec, maximize=True, skip_tn=True, n_total=n_global, comm=comm,
+                               use_shadow=use_shadow)
+        finally:
+            if not packed:
+                os.environ.pop("XCOLUMNS_BCA_PACKED", None)
+        if args.exchanges:
+            eng.exchanges = max(1, args.exchanges)
+        n_local = hi - lo
+        policy = WavePolicy(n_local, fixed=args.waves if args.waves > 0 else None, world=world, k=K)  # as _bc_csr builds it
+        # the reference's visiting order over the GLOBAL rows (np.random.default_rng(seed), cumulative
+        # shuffles, block_coordinate.py:413-419), restricted to this rank's block
+        rng = np.random.default_rng(ORDER_SEED)
+        order = np.arange(n_global)
+        orders = torch.empty((total_sweeps, n_local), dtype=torch.int32, device=dev)
+        for s in range(total_sweeps):
+            rng.shuffle(order)
+            orders[s] = torch.from_numpy(local_order(order, lo, hi)).to(dev)
+        return eng, policy, orders, n_local, n_global, Y
+
+    def one_mode(scaling, zipf, repeats, use_shadow=None, packed=True):
+        eng, policy, orders, n_local, n_global, Y = build(scaling, zipf, use_shadow, packed)
+        if comm is not None:
+            comm.bytes_reduced = comm.calls = 0
+        t = Timer(eng, policy, orders, n_local, n_global, m, comm, world, dev)
+        res = t.measure(args.warmup, args.steps, repeats)
+        res.update(n_local=n_local, n_global=n_global, Y=Y, eng=eng,
+                   pipelined=eng.can_pipeline(n_local) and not policy.sequential,
+                   exchanges=eng.exchanges, hot=eng.hot_labels is not None)
+        if comm is not None:
+            per_sweep = max(1, (args.warmup + args.steps * repeats))
+            res["comm"] = {"backend": backend, "world_size": dist.get_world_size(),
+                           "all_reduce_bytes_per_sweep": (2 * m + 1) * 8 + (eng.exchanges - 1) * 2 * m * 4
+                           if eng.shadow is not None else (2 * m + 1) * 8,
+                           "all_reduce_calls_total": comm.calls, "all_reduce_bytes_total": comm.bytes_reduced,
+                           "all_reduce_ms_per_sweep": (_median([x / args.steps for x in res["allreduce_ms"]])
+                                                       if res["allreduce_ms"] else None),
+                           "sweeps_run": per_sweep}
+        return res
+
+    main = one_mode(args.scaling, args.zipf, args.repeats)
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_extras:
+        main["eng"].close()
+        del main["eng"]
+        torch.cuda.empty_cache()
+        strong = one_mode("strong", args.zipf, max(1, min(args.repeats, 3)))
+
+    out = None
+    if rank == 0:
+        b_sweep = algorithmic_bytes_per_row_sweep(R_NNZ, K)
+        el = main["elapsed"]
+        med = _median(el)
+        n_local, n_global = main["n_local"], main["n_global"]
+        roof = {"kernel": "bca_sweep_csr_kernel<float,1,false,true,true,true,%s> (one launch = one sweep of the rank's rows, "
+                          "from-scratch recompute fused)" % ("true" if main["hot"] else "false"),
+                "bound": "hbm"}
+        if main["kernel_ms"]:
+            roof.update(roofline_of(main["kernel_ms"], n_local))
+        else:
+            roof.update({"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (tools/profile_bench.sh -> tools/summarize_profile.py), when present
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_zipf' if args.zipf else ''}.json")
+        if os.path.exists(tfile) and world == 1:
+            try:
+                traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        roof.update({
+            "traffic": traffic,
+            "algorithmic_bytes_per_row": b_sweep,
+            "algorithmic_bytes_note": "SURVEY 8(d) B_sweep = step pass 1644 (incl. 24r B of float64 statistic gathers) + fused "
+                                      "from-scratch recompute 424; the timed kernel gathers 8-byte float32 records instead "
+                                      "(see config.arithmetic, frac_f64_records)",
+            "frac_whole_step": b_sweep * n_global * args.steps / med / 1e9 / (HBM_PEAK_GBS * world),
+        })
+        out = {
+            "metric": "BCA iterations/sec x instances (rows/s) at k=5",
+            "value": n_global * args.steps / med,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": med / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f64 gains/accumulation on f32 gathered records",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: CSR n={n_local} rows/GPU ({n_global} over {world} GPU(s), {args.scaling} scaling), "
+                            f"m={m} labels, {R_NNZ} entries/row, {'Zipf(1)' if args.zipf else 'uniform'} label popularity, "
+                            f"BCA macro-F1 k={K}, init top-k, skip_tn, float32 scores",
+                "arithmetic": "gathered per-label statistics: float32 {tp, fp} shadow records (8 B) + float32 column sum "
+                              "streamed with the row; gains, top-k keys, accumulation (acc, tpfp) and utility in float64; "
+                              "the reference gathers float64 statistics (types.py:14) -- that variant is roofline.frac_f64_records",
+                "rows_per_gpu": n_local, "rows_total": n_global, "labels": m, "nnz_per_row": R_NNZ, "k": K,
+                "concurrent_wavefronts_per_sweep": main["waves"],
+                "parity_policy": os.environ.get("XCOLUMNS_BCA_PARITY", "per_sweep"),
+                "exchanges_per_sweep": main["exchanges"],
+                "step": "sweep kernel (incl. from-scratch tp/fp recompute) + (all-reduce) + commit/utility "
+                        "+ stopping rule + D2H of the result",
+            },
+            "repeats": {"n": len(el), "ms_per_step_median": med / args.steps * 1e3,
+                        "ms_per_step_min": min(el) / args.steps * 1e3, "ms_per_step_max": max(el) / args.steps * 1e3,
+                        "note": "each repeat = reset to the top-k prediction (untimed), barrier, K sweeps, barrier; "
+                                "value and ms_per_step are the median repeat"},
+            "roofline": roof,
+            "host_ms_per_step": {"enqueue_sweep_and_boundary": main["host_t"]["enqueue"],
+                                 "wait_for_previous_result": main["host_t"]["wait_result"]},
+            "loop": "device-side stopping rule, host one iteration behind" if main["pipelined"] else "host-paced (exact)",
+            "utility_by_sweep": main["utilities"],
+            "utility_top_k": main["u_top_k"],
+        }
+        if "comm" in main:
+            out["comm"] = main["comm"]
+        if strong is not None:
+            sm = _median(strong["elapsed"])
+            out["strong_scaling"] = {
+                "value": strong["n_global"] * args.steps / sm, "unit": "rows/s", "ms_per_step": sm / args.steps * 1e3,
+                "rows_per_gpu": strong["n_local"], "rows_total": strong["n_global"],
+                "roofline_frac_per_gpu": (roofline_of(strong["kernel_ms"], strong["n_local"])["frac"]
+                                          if strong["kernel_ms"] else None),
+                "kernel_ms_by_sweep": (roofline_of(strong["kernel_ms"], strong["n_local"])["kernel_ms_by_sweep"]
+                                       if strong["kernel_ms"] else None),
+                "comm": strong.get("comm"),
+                "note": "the SAME n-row workload matrix split over the ranks (BASELINE configs[3] style); "
+                        "speed-up = this value / the N=1 value",
+            }
+
+    if extras and rank == 0:
+        Y = main["Y"]
+        main["eng"].close()
+        del main["eng"]
+        torch.cuda.empty_cache()
+        # (1) the same loop on the reference's float64 records: no float32 shadow, no packed float32 stream
+        try:
+            f64 = one_mode(args.scaling, args.zipf, 1, use_shadow=False, packed=False)
+            r64 = roofline_of(f64["kernel_ms"], f64["n_local"])
+            out["roofline"]["frac_f64_records"] = r64["frac"]
+            out["roofline"]["f64_records"] = {"avg_kernel_ms": r64["avg_kernel_ms"], "frac_by_sweep": r64["frac_by_sweep"],
+                                              "value": f64["n_global"] * args.steps / f64["elapsed"][0],
+                                              "kernel": "bca_sweep_csr_kernel<float,1,false,true,false,false,false>: 16-byte "
+                                                        "float64 {tp, fp} records gathered, float64 s streamed (XCOLUMNS_BCA_SHADOW=0 "
+                                                        "XCOLUMNS_BCA_PACKED=0)",
+                                              "utility_by_sweep": f64["utilities"]}
+            f64["eng"].close()
+            del f64
+            torch.cuda.empty_cache()
+        except Exception as e:  # an extra must never cost the main line
+            out["roofline"]["frac_f64_records"] = None
+            out["roofline"]["f64_records_error"] = repr(e)
+        # (2) BASELINE.md section 4's quantity: ONE public call, fixed number of sweeps
+        try:
+            out["api_call"] = api_call_leg(Y, args.steps)
+        except Exception as e:
+            out["api_call"] = {"error": repr(e)}
+        # (3) the same workload with Zipf(1) label popularity (real XMLC data is long-tailed)
+        if not args.zipf and not args.no_zipf:
+            try:
+                z = one_mode(args.scaling, True, max(1, min(args.repeats, 3)))
+                rz = roofline_of(z["kernel_ms"], z["n_local"])
+                zm = _median(z["elapsed"])
+                out["zipf"] = {"value": z["n_global"] * args.steps / zm, "unit": "rows/s", "ms_per_step": zm / args.steps * 1e3,
+                               "roofline_frac": rz["frac"], "avg_kernel_ms": rz["avg_kernel_ms"],
+                               "kernel_ms_by_sweep": rz["kernel_ms_by_sweep"], "frac_by_sweep": rz["frac_by_sweep"],
+                               "concurrent_wavefronts_per_sweep": z["waves"], "utility_by_sweep": z["utilities"],
+                               "workload": f"{args.workload} with Zipf(1) label popularity over a random permutation of the labels"}
+                z["eng"].close()
+                del z
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["zipf"] = {"error": repr(e)}
+        # (4) per-sweep |utility - sequential oracle| of the default policy on configs[1] (C2: the oracle takes seconds)
+        try:
+            out["parity_c2"] = parity_leg()
+        except Exception as e:
+            out["parity_c2"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Y, K, seed=ORDER_SEED)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(main["Y"], K, seed=ORDER_SEED)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def api_call_leg(Y, sweeps):
+    """rows/s of ONE predict_optimizing_macro_f1_score_using_bc(y_proba, k, tolerance < 0, max_iters = K) call:
+    BASELINE.md section 4's definition of the metric (wall time of the call; the reference's numpy visiting
+    order, the drop-in default).  From a scipy matrix in host memory (upload over PCIe included) and from a
+    matrix already resident in HBM (xcolumns_amd.DeviceCSR)."""
+    import torch
+
+    from xcolumns_amd import _device as D
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+
+    n = Y.shape[0]
+    res = {"sweeps": sweeps, "order": "numpy default_rng stream (drop-in default)"}
+    for name, inp in (("host_csr_matrix", Y), ("device_resident", D.DeviceCSR.from_scipy(Y))):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, meta = f(inp, K, tolerance=-1.0, max_iters=sweeps, seed=ORDER_SEED, return_meta=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        assert meta["iters"] == sweeps
+        res[name] = {"ms": best * 1e3, "rows_per_s": n * sweeps / best}
+    return res
+
+
+def parity_leg():
+    """Default policy against the sequential oracle on BASELINE configs[1] (100K x 30K, uniform and Zipf),
+    5 sweeps: |utility difference| after every sweep."""
+    from oracle import ref as oracle_ref
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+    from xcolumns_amd.synthetic import WORKLOADS, make_csr
+
+    n, m = WORKLOADS["c2_100Kx30K"]
+    out = {"workload": "c2_100Kx30K, 5 sweeps, seed 13, default policy", "bar": 1e-5}
+    for name, zipf in (("uniform", False), ("zipf", True)):
+        Y = make_csr(n, m, R_NNZ, seed=MATRIX_SEED, zipf=zipf, k=K)
+        metric = oracle_ref.make_metric(oracle_ref.FBETA, k=float(K), m=float(m))
+        _, mo = oracle_ref.predict_using_bc_with_0approx(Y, metric, K, skip_tn=True, seed=ORDER_SEED, max_iters=5, tolerance=-1.0)
+        _, mg = f(Y, K, tolerance=-1.0, max_iters=5, seed=ORDER_SEED, return_meta=True)
+        d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+        out[name] = {"abs_diff_by_sweep": [float(x) for x in d], "max": float(d.max())}
+    return out
 
 
 def main():
@@ -85,212 +603,22 @@ def main():
     ap.add_argument("--workload", default="ns_1Mx500K",
                     help="ns_1Mx500K (the configuration north_star's targets are quoted on; default), "
                          "c2_100Kx30K (BASELINE configs[1]), c3_..., c4_...")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank holds the workload's n rows; strong: the n rows are split over the ranks")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1) label popularity instead of uniform")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts walking the order (0 = product default)")
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K-sweep timed region (median reported)")
+    ap.add_argument("--exchanges", type=int, default=0, help="N > 1: exchanges of the ranks' changes per sweep (0 = product default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-zipf", action="store_true", help="skip the Zipf leg of the default run")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the main timed loop (profiling runs): no f64-record / API / Zipf / parity legs, no strong_scaling object")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    from xcolumns_amd import _device as D
-    from xcolumns_amd import _lib
-    from xcolumns_amd.block_coordinate import BcaCsrEngine, WavePolicy
-    from xcolumns_amd.distributed import TorchComm
-    from xcolumns_amd.metrics import MetricSpec
-    from xcolumns_amd.synthetic import WORKLOADS, make_csr
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    # XC_BENCH_BACKEND=gloo + XC_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow with
-    # several ranks on ONE GPU (RCCL refuses duplicate devices); never used for numbers.
-    one_device = os.environ.get("XC_BENCH_ONE_DEVICE") == "1"
-    torch.cuda.set_device(0 if one_device else local_rank)
-    comm = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("XC_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-        comm = TorchComm()
-
-    n, m = WORKLOADS[args.workload]
-    seed = 20240001 + rank
-    Y = make_csr(n, m, R_NNZ, seed=seed, zipf=args.zipf, k=K)
-    dev = D.require_gpu()
-    csr = D.DeviceCSR.from_scipy(Y, dev)
-    spec = MetricSpec(base=_lib.XC_M_FBETA)  # macro-F1: binary_f1_score_on_conf_matrix, eps 1e-9
-    eng = BcaCsrEngine(csr, K, spec, spec, maximize=True, skip_tn=True, n_total=n * world, comm=comm)
-    policy = WavePolicy(n, fixed=args.waves if args.waves > 0 else None, world=world, k=K)   # as _bc_csr builds it
-    n_u = n * world   # normalisation of the utility = global row count
-
-    # visiting orders of every sweep, the reference's RNG stream (seed 13), uploaded up front
-    total = args.warmup + args.steps
-    rng = np.random.default_rng(13 + rank)
-    order = np.arange(n)
-    orders = torch.empty((total, n), dtype=torch.int32, device=dev)
-    for s in range(total):
-        rng.shuffle(order)
-        orders[s] = torch.from_numpy(order.astype(np.int32)).to(dev)
-
-    eng.init_top()
-    eng.reset_state(greedy=False)
-    u0 = eng.recompute_utility_sum(n_u) / m
-
-    ev_pairs = []
-    waves_used = []
-    # events are created up front: only their attachment to the sweep dispatch is in the timed region
-    ev_pool = []
-    for _ in range(args.steps):
-        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.call("xc_event_create", ctypes.byref(e0))
-        _lib.call("xc_event_create", ctypes.byref(e1))
-        ev_pool.append((e0, e1))
-    host_t = {"enqueue": 0.0, "wait_result": 0.0}
-    pipelined = eng.can_pipeline(n) and not policy.sequential
-    NEVER = -1e300  # tolerance: the stopping rule never fires, every run does exactly K sweeps
-
-    def run(first, last, old_sum, timed):
-        """Sweeps first..last-1 exactly as block_coordinate.run_bca_sweeps drives them: the stopping
-        rule and the wavefront policy are evaluated on the GPU at every boundary, the host enqueues
-        sweep j + 1 before it reads the result of sweep j (one D2H of 4 doubles per boundary)."""
-        out = []
-        if first >= last:
-            return out
-        if not pipelined:   # bca_waves = 1 (--waves 1): the host-paced exact loop
-            changed = None
-            for s in range(first, last):
-                if timed and os.environ.get("XC_BENCH_NO_EVENTS") != "1":
-                    e0, e1 = ev_pool[len(ev_pairs)]
-                    _lib.call("xc_bca_time_next_sweep", e0, e1)
-                    ev_pairs.append((e0, e1))
-                w = policy.next(changed)
-                eng.sweep(orders[s], n, w, greedy=False)
-                out.append(eng.recompute_utility_sum(n_u))
-                changed = eng.rows_changed()
-                if timed:
-                    waves_used.append(w)
-            return out
-        eng.pipeline_begin(old_sum, NEVER, float(m), True, policy, policy.next(None))
-
-        def collect(j):
-            t = time.perf_counter()
-            total, changed, waves, flag = eng.pipeline_result(j)
-            if timed:
-                host_t["wait_result"] += time.perf_counter() - t
-                waves_used.append(waves)
-            assert flag == 0, flag
-            out.append(total)
-
-        for s in range(first, last):
-            t = time.perf_counter()
-            if timed and os.environ.get("XC_BENCH_NO_EVENTS") != "1":
-                # HIP events attached to the sweep dispatch itself, on the stream it runs on
-                e0, e1 = ev_pool[len(ev_pairs)]
-                _lib.call("xc_bca_time_next_sweep", e0, e1)
-                ev_pairs.append((e0, e1))
-            eng.pipeline_step(orders[s], s, n_u)
-            if timed:
-                host_t["enqueue"] += time.perf_counter() - t
-            if s > first:
-                collect(s - 1)
-        collect(last - 1)
-        return out
-
-    u0_sum = u0 * m
-    run(0, args.warmup, u0_sum, False)
-    # the timed steps are sweeps 1..K of a fresh run: back to the top-k prediction
-    # (untimed), so the measured mix of changed / unchanged rows is a real run's
-    eng.init_top()
-    u0_sum = eng.recompute_utility_sum(n_u)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    utilities = [u / m for u in run(args.warmup, total, u0_sum, True)]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    sweep_ms = []
-    for a, b in ev_pairs:
-        ms = ctypes.c_float(0.0)
-        _lib.call("xc_event_elapsed_ms", a, b, ctypes.byref(ms))
-        sweep_ms.append(ms.value)
-        _lib.call("xc_event_destroy", a)
-        _lib.call("xc_event_destroy", b)
-    avg_sweep_s = (sum(sweep_ms) / len(sweep_ms)) / 1e3 if sweep_ms else float("nan")
-
-    if rank == 0:
-        b_step = algorithmic_bytes_per_row_step(R_NNZ, K)
-        b_sweep = algorithmic_bytes_per_row_sweep(R_NNZ, K)
-        achieved = b_sweep * n / avg_sweep_s / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same
-        # command (tools/profile_bench.sh -> tools/summarize_profile.py), when present
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}{'_zipf' if args.zipf else ''}.json")
-        if os.path.exists(tfile) and world == 1:
-            try:
-                traffic = json.load(open(tfile))["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "BCA iterations/sec x instances (rows/s) at k=5",
-            "value": n * world * args.steps / elapsed,
-            "unit": "rows/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: CSR n={n} rows/GPU, m={m} labels, {R_NNZ} entries/row, "
-                            f"{'Zipf(1)' if args.zipf else 'uniform'} label popularity, BCA macro-F1 k={K}, "
-                            f"init top-k, skip_tn, float32 scores, float64 statistics",
-                "rows_per_gpu": n, "labels": m, "nnz_per_row": R_NNZ, "k": K,
-                "concurrent_wavefronts_per_sweep": waves_used,
-                "step": "sweep kernel (incl. from-scratch tp/fp recompute) + (all-reduce) + commit/utility "
-                        "+ stopping rule + D2H of the result",
-            },
-            "roofline": {
-                "kernel": "bca_sweep_csr_kernel<float,1>",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_row": b_sweep,
-                "algorithmic_bytes_note": "SURVEY 8(d) B_sweep = step pass 1644 + fused from-scratch recompute 424",
-                "frac_step_pass_only": b_step * n / avg_sweep_s / 1e9 / HBM_PEAK_GBS,
-                "frac_whole_step": b_sweep * n * world * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
-                "avg_kernel_ms": avg_sweep_s * 1e3,
-            },
-            "host_ms_per_step": {"enqueue_sweep_and_boundary": host_t["enqueue"] / args.steps * 1e3,
-                                 "wait_for_previous_result": host_t["wait_result"] / args.steps * 1e3},
-            "loop": "device-side stopping rule, host one iteration behind" if pipelined else "host-paced (exact)",
-            "utility_first_last": [utilities[0], utilities[-1]],
-            "utility_top_k": u0,
-        }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(Y, K, seed=13)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.repeats < 1:
+        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --repeats >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(args.gpus))
+    worker(args)
 
 
 if __name__ == "__main__":

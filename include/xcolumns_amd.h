@@ -301,10 +301,15 @@ int xc_event_destroy(void *ev);
 int xc_event_elapsed_ms(void *start, void *stop, float *ms_host);
 int xc_bca_time_next_sweep(void *start, void *stop);
 
-/* Concurrent sweeps re-read, before committing a changed row, the records of the
- * labels it adds or drops and re-score the row if another wavefront moved them
- * (optimistic validation; default on).  Process-wide switch, mainly for studies. */
-int xc_bca_set_validation(int on);
+/* How a concurrent sweep guards a row that CHANGES its prediction against other rows in flight
+ * that change the same labels (process-wide switch, mainly for studies):
+ *   2 (default)  commit protocol: the deltas of the labels the row adds or drops are pushed with
+ *                RETURNING atomics and the returned values compared with the records the row was
+ *                scored on; a difference means another row changed that label first, and the row is
+ *                processed again on fresh records (its new prediction is what memory holds by then);
+ *   1            round-1 form: re-read those records before committing, re-score if they moved;
+ *   0            none. */
+int xc_bca_set_validation(int mode);
 
 /* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */

@@ -54,7 +54,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     src_newer = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("xc_oracle.c", "xc_oracle_impl.h")
+        for f in ("xc_oracle.c", "xc_oracle_impl.h", "xc_oracle_mt_impl.h", "Makefile")
     )
     if force or src_newer:
         subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
@@ -146,6 +146,37 @@ def predict_weighted_per_instance(y_proba, k: int, th: float = 0.0, a=None, b=No
 
 def predict_top_k(y_proba, k: int, keep_scores: bool = False):
     return predict_weighted_per_instance(y_proba, k, keep_scores=keep_scores)
+
+
+def predict_top_k_threads(y_proba: csr_matrix, k: int, n_threads: int) -> csr_matrix:
+    """predict_top_k on a csr_matrix with the loop over rows split over `n_threads` OpenMP threads:
+    the reference under XCOLUMNS_NUMBA_PARALLEL=1 (numba_csr_functions.py:604 `prange`).  Baseline
+    leg of bench.py; same result as the serial form."""
+    n, m = y_proba.shape
+    dt = y_proba.dtype
+    indptr, indices, data = _csr_parts(y_proba)
+    out_idx = np.empty(n * k, dtype=np.int32)
+    out_dat = np.empty(n * k, dtype=dt)
+    getattr(lib(), "oracle_topk_csr_mt" + _sfx(dt))(
+        ctypes.c_int64(n), _p(indptr), _p(indices), _p(data), ctypes.c_int(k), None, None, ctypes.c_int(0),
+        _p(out_idx), _p(out_dat), ctypes.c_int(int(n_threads)))
+    out_indptr = (np.arange(n + 1, dtype=np.int64) * k).astype(y_proba.indptr.dtype)
+    return csr_matrix((out_dat, out_idx.astype(y_proba.indices.dtype), out_indptr), shape=(n, m))
+
+
+def calculate_confusion_matrix_threads(y_true: csr_matrix, y_pred: csr_matrix, n_threads: int):
+    """(tp, fp, fn) of calculate_confusion_matrix on CSR input, rows split over `n_threads` OpenMP
+    threads with per-thread column vectors (numba_csr_functions.py:166 / :242 `prange`).  Sums are
+    formed in another order than the serial pass: equal to rounding only."""
+    n, m = y_true.shape
+    dt = y_true.dtype
+    tp, fp, fn = (np.empty(m, dtype=np.float64) for _ in range(3))
+    t_indptr, t_indices, t_data = _csr_parts(y_true)
+    p_indptr, p_indices, p_data = _csr_parts(y_pred.astype(dt))
+    getattr(lib(), "oracle_confusion_csr_mt" + _sfx(dt))(
+        ctypes.c_int64(n), ctypes.c_int64(m), _p(t_indptr), _p(t_indices), _p(t_data), _p(p_indptr), _p(p_indices),
+        _p(p_data), _p(tp), _p(fp), _p(fn), ctypes.c_int(int(n_threads)))
+    return tp, fp, fn
 
 
 # ---------------------------------------------------------------------------

@@ -23,7 +23,7 @@ from xcolumns_amd.synthetic import make_csr  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 30_000
 zipf = len(sys.argv) > 3 and sys.argv[3] == "zipf"
-_lib.load().xc_bca_set_validation(int(os.environ.get("XC_VALIDATE", "1")))
+_lib.load().xc_bca_set_validation(int(os.environ.get("XC_VALIDATE", "2")))
 r, k, sweeps = 50, 5, 5
 Y = make_csr(n, m, r, seed=20240001, zipf=zipf)
 t0 = time.time()

@@ -18,8 +18,14 @@ from xcolumns_amd.synthetic import make_csr  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 30_000
 zipf = len(sys.argv) > 3 and sys.argv[3] == "zipf"
-k, sweeps = 5, 8
-Y = make_csr(n, m, 50, seed=20240001, zipf=zipf)
+k, sweeps = 5, int(os.environ.get("XC_STUDY_SWEEPS", "8"))
+repeats = int(os.environ.get("XC_STUDY_REPEATS", "1"))
+budgets = [float(x) for x in os.environ.get("XC_STUDY_BUDGETS", "1e-3,2e-3,4e-3,8e-3,1.0").split(",")]
+if n > 200_000:
+    from xcolumns_amd.synthetic import make_csr_rows
+    Y = make_csr_rows(n, m, 0, n, 50, seed=20240001, zipf=zipf)
+else:
+    Y = make_csr(n, m, 50, seed=20240001, zipf=zipf)
 metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
 _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=sweeps, tolerance=-1.0)
 uo = np.asarray(mo["utilities"])
@@ -33,7 +39,7 @@ for s in range(sweeps):
     rng0.shuffle(order)
     orders.append(torch.from_numpy(order.astype(np.int32)).to(dev))
 print(f"{n}x{m} zipf={zipf}; oracle utilities {uo.tolist()}")
-for budget in (1e-3, 2e-3, 4e-3, 8e-3, 1.0):
+for budget in [b for b in budgets for _ in range(repeats)]:
     eng = BcaCsrEngine(csr, k, spec, spec, skip_tn=True)
     eng.init_top()
     eng.reset_state(False)

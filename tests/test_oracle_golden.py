@@ -163,3 +163,22 @@ def test_coverage_bca_golden():
         np.testing.assert_allclose(meta["utilities"], z[f"c{ci}_utilities"], rtol=0, atol=tol, err_msg=name)
         np.testing.assert_array_equal(P.indices, z[f"c{ci}_pred_indices"], err_msg=name)
         assert P.dtype == Y.dtype and (np.diff(P.indptr) == spec["k"]).all()
+
+
+def test_threaded_baseline_legs_equal_the_serial_oracle(oref):
+    """The OpenMP row-parallel top-k / confusion passes (bench.py's T = 8 / all-core CPU baseline legs,
+    the reference's prange loops) give the serial oracle's results: index sets bit-exact, column sums
+    to rounding."""
+    from xcolumns_amd.synthetic import make_csr
+
+    for dtype in (np.float32, np.float64):
+        Y = make_csr(3000, 400, 30, seed=5, k=4, dtype=dtype)
+        P = oref.predict_top_k(Y, 4)
+        for t in (1, 3, 8):
+            Pt = oref.predict_top_k_threads(Y, 4, t)
+            assert np.array_equal(P.indices, Pt.indices) and np.array_equal(P.indptr, Pt.indptr)
+            tp, fp, fn, _ = oref.calculate_confusion_matrix(Y, P, skip_tn=True)
+            tpt, fpt, fnt = oref.calculate_confusion_matrix_threads(Y, P, t)
+            np.testing.assert_allclose(tpt, tp, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(fpt, fp, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(fnt, fn, rtol=0, atol=1e-9)

@@ -9,3 +9,10 @@ hand-written HIP kernels for gfx950 behind the C ABI of ``include/xcolumns_amd.h
 There is no CPU fallback: without the built library and a GPU the calls raise.
 """
 __version__ = "0.1.0"
+
+
+def __getattr__(name):   # lazily: importing the package must not import torch
+    if name == "DeviceCSR":
+        from ._device import DeviceCSR
+        return DeviceCSR
+    raise AttributeError(f"module 'xcolumns_amd' has no attribute {name!r}")

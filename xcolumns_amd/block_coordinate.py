@@ -49,7 +49,7 @@ from .metrics import (
     binary_recall_on_conf_matrix,
     resolve_metric,
 )
-from .types import DenseMatrix, Matrix, is_dense, is_matrix
+from .types import DenseMatrix, Matrix, is_dense, is_matrix, is_sparse
 from .utils import add_kwargs_to_signature, log_info, log_warning, random_at_k_csr, random_at_k_np
 from .weighted_prediction import topk_csr_device, topk_dense_device
 
@@ -143,6 +143,12 @@ class BcaCsrEngine:
                  comm=None, use_shadow: Optional[bool] = None):
         if k < 1 or k > _lib.XC_MAX_K:
             raise ValueError(f"k must be in 1..{_lib.XC_MAX_K} for sparse y_proba on the GPU, got {k}")
+        if csr.n > 0 and csr.min_row_nnz < k:
+            # a short row would leave stale ids in its prediction slots and make the sweep read before
+            # the row's first entry (xc_bca.hip load_row): refuse it here, whoever builds the engine
+            raise ValueError(
+                f"every row of a sparse y_proba must store at least k={k} entries on the GPU path "
+                f"(shortest row has {int(csr.min_row_nnz)})")
         self.csr = csr
         self.k = int(k)
         self.gain_metric = gain_spec.to_c()
@@ -240,12 +246,6 @@ class BcaCsrEngine:
             _lib.load().xc_bca_plan_destroy(self._plan)
             self._plan = None
             self._plan_key = None
-
-    def __del__(self):
-        try:
-            self._drop_plan()
-        except Exception:
-            pass
 
     # -- statistics -------------------------------------------------------------
     def reset_state(self, greedy: bool):
@@ -412,11 +412,20 @@ class BcaCsrEngine:
             self._changed_last = int(round(changed))
         return total, int(round(changed)), int(waves), int(flag)
 
+    def close(self):
+        """Release what the engine holds outside torch's allocator: the C-side plan and the pinned
+        result ring (after the stream has drained: the boundary kernels write into it)."""
+        self._drop_plan()
+        if getattr(self, "_ring_ptr", None) is not None:
+            torch.cuda.synchronize()
+            _lib.call("xc_host_free_pinned", self._ring_ptr)
+            self._ring_ptr = None
+            self._ring = None
+            self._ctrl = None
+
     def __del__(self):
         try:
-            if getattr(self, "_ctrl", None) is not None:
-                torch.cuda.synchronize()
-                _lib.call("xc_host_free_pinned", self._ring_ptr)
+            self.close()
         except Exception:
             pass
 
@@ -561,43 +570,59 @@ def _run_pipelined(eng, next_order: Callable, n_u: int, div: float, maximize: bo
     collect(max_iters)
 
 
-def _initial_csr_indices(y_proba: csr_matrix, init_y_pred, k: int, seed) -> Optional[np.ndarray]:
-    """block_coordinate.py:28-51 for CSR input; None means "top" (done on the GPU)."""
-    n, m = y_proba.shape
+def _initial_csr_indices(y_proba, init_y_pred, k: int, seed):
+    """block_coordinate.py:28-51 for sparse input; None means "top" (done on the GPU).  Returns the
+    k column ids per row as a numpy array (host input) or an int32 tensor (device-resident input)."""
+    n, m = tuple(y_proba.shape)
     if isinstance(init_y_pred, str) and init_y_pred in ("random", "greedy"):
-        mat = random_at_k_csr((n, m), k, dtype=y_proba.dtype, seed=seed)
+        dt = y_proba.dtype if isinstance(y_proba, (csr_matrix, D.DeviceCSR)) else D.numpy_dtype(y_proba.dtype)
+        mat = random_at_k_csr((n, m), k, dtype=dt, seed=seed)
         return mat.indices
     if isinstance(init_y_pred, str) and init_y_pred == "top":
         return None
     if is_matrix(init_y_pred):
-        if init_y_pred.shape != (n, m):
-            raise ValueError(f"init_y_pred must have shape (n, m) = ({n}, {m}), but has shape {init_y_pred.shape}")
-        if not isinstance(init_y_pred, csr_matrix):
-            raise ValueError("init_y_pred must be a csr_matrix when y_proba is a csr_matrix")
-        if not (np.diff(init_y_pred.indptr) == k).all():
+        if tuple(init_y_pred.shape) != (n, m):
+            raise ValueError(f"init_y_pred must have shape (n, m) = ({n}, {m}), but has shape {tuple(init_y_pred.shape)}")
+        if isinstance(y_proba, csr_matrix):
+            if not isinstance(init_y_pred, csr_matrix):
+                raise ValueError("init_y_pred must be a csr_matrix when y_proba is a csr_matrix")
+            if not (np.diff(init_y_pred.indptr) == k).all():
+                raise ValueError(
+                    "on the GPU path init_y_pred must hold exactly k stored entries per row "
+                    "(variable-length rows are not supported)")
+            return init_y_pred.indices
+        if not D.is_device_sparse(init_y_pred):
+            raise ValueError("init_y_pred must be a DeviceCSR / torch sparse_csr tensor when y_proba is one")
+        init = D.as_device_csr(init_y_pred)
+        if n > 0 and not (init.min_row_nnz == init.max_row_nnz == k):
             raise ValueError(
                 "on the GPU path init_y_pred must hold exactly k stored entries per row "
                 "(variable-length rows are not supported)")
-        return init_y_pred.indices
+        return init.indices
     raise ValueError(
         "init_y_pred must be np.ndarray, Torch.tensor, csr_matrix or str in ['random', 'greedy', 'top'], "
         f"but has type {type(init_y_pred)}")
 
 
-def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
+def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
             init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves, order_backend):
-    n_rows, m = y_proba.shape
+    """Sparse y_proba: a csr_matrix in host memory (uploaded here, result downloaded) or a matrix already
+    resident in HBM -- DeviceCSR or torch sparse_csr tensor -- in which case nothing crosses PCIe but the
+    visiting orders and the per-sweep utility."""
+    n_rows, m = tuple(y_proba.shape)
+    host = isinstance(y_proba, csr_matrix)
     if k == 0:
         raise NotImplementedError(
             "k=0 (no budget) with sparse y_proba is not implemented on the GPU path yet; "
             "pass a dense y_proba or k > 0")
-    row_nnz = np.diff(y_proba.indptr)
-    if n_rows > 0 and row_nnz.min() < k:
-        raise ValueError(
-            f"every row of a sparse y_proba must store at least k={k} entries on the GPU path "
-            f"(shortest row has {int(row_nnz.min())})")
+    if host:
+        row_nnz = np.diff(y_proba.indptr)
+        if n_rows > 0 and row_nnz.min() < k:
+            raise ValueError(
+                f"every row of a sparse y_proba must store at least k={k} entries on the GPU path "
+                f"(shortest row has {int(row_nnz.min())})")
     dev = D.require_gpu()
-    csr = D.DeviceCSR.from_scipy(y_proba, dev)
+    csr = D.as_device_csr(y_proba, dev)
     eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn)
 
     log_info("  Initializing initial prediction ...", verbose)
@@ -606,7 +631,10 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
     if init_idx is None:
         eng.init_top()
     else:
-        init_dev = torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)).to(dev)
+        if isinstance(init_idx, torch.Tensor):
+            init_dev = init_idx.to(device=dev, dtype=torch.int32).clone()
+        else:
+            init_dev = torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)).to(dev)
         D.check_column_ids(init_dev, m, "init_y_pred")
         eng.init_indices(init_dev)
 
@@ -626,7 +654,19 @@ def _bc_csr(y_proba: csr_matrix, gain_spec, utility_spec, k, metric_aggregation,
     run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                    policy, verbose, meta)
 
-    new_indices = eng.pred_idx.cpu().numpy()
+    pred_idx = eng.pred_idx
+    eng.close()
+    if not host:
+        # device-resident input -> device-resident prediction of the same kind; an explicit init_y_pred is
+        # updated in place and returned, like the reference does with its matrices (:46, :285-287)
+        if isinstance(init_y_pred, D.DeviceCSR):
+            init_y_pred.indices.copy_(pred_idx)
+            return init_y_pred
+        if D.is_torch_sparse_csr(init_y_pred):
+            init_y_pred.col_indices().copy_(pred_idx.to(init_y_pred.col_indices().dtype))
+            return init_y_pred
+        return D.fixed_width_prediction(y_proba, pred_idx, k, n_rows, m)
+    new_indices = pred_idx.cpu().numpy()
     if isinstance(init_y_pred, csr_matrix):
         # the reference updates an explicit init_y_pred in place and returns it (:46, :285-287)
         init_y_pred.indices[:] = new_indices.astype(init_y_pred.indices.dtype, copy=False)
@@ -804,7 +844,7 @@ def predict_using_bc_with_0approx(
 
     if not isinstance(k, int):
         raise ValueError("k must be an integer")
-    if not (is_dense(y_proba) or isinstance(y_proba, csr_matrix)):
+    if not (is_dense(y_proba) or is_sparse(y_proba)):
         raise ValueError("y_proba must be either np.ndarray, torch.Tensor, or csr_matrix")
     if metric_aggregation not in ("mean", "sum"):
         raise ValueError(
@@ -823,7 +863,7 @@ def predict_using_bc_with_0approx(
     bca_diagnostics = kwargs.pop("bca_diagnostics", False)
     order_backend = kwargs.pop("order_backend", os.environ.get("XCOLUMNS_ORDER_BACKEND", "numpy"))
 
-    if isinstance(y_proba, csr_matrix):
+    if is_sparse(y_proba):
         y_pred = _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                          init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves,
                          order_backend)

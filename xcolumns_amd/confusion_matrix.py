@@ -120,13 +120,18 @@ def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
     """Validation of confusion_matrix.py:237-268, then the fused kernel.
     Returns (tp, fp, fn) float64 torch tensors on the GPU, and a converter that
     puts a result vector back where the inputs live."""
+    on_device = False
     if is_dense(y_true) and is_dense(y_pred):
         dense = True
     elif isinstance(y_true, csr_matrix) and isinstance(y_pred, csr_matrix):
         dense = False
+    elif D.is_device_sparse(y_true) and D.is_device_sparse(y_pred):
+        # both already resident in HBM (DeviceCSR / torch sparse_csr): no host round trip, the result
+        # vectors are torch tensors on the GPU
+        dense, on_device = False, True
     else:
         raise ValueError("y_true and y_pred must be both np.ndarray, both torch.Tensor, or csr_matrix")
-    if y_true.shape != y_pred.shape:
+    if tuple(y_true.shape) != tuple(y_pred.shape):
         raise ValueError("y_true and y_pred must have the same shape")
     if axis not in (0, 1):
         raise ValueError("axis must be 0 or 1")
@@ -143,6 +148,16 @@ def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
             yt, yp = yt.t().contiguous(), yp.t().contiguous()
         stats = confusion_dense_device(yt, yp)
         home = y_true.device if is_torch else None
+    elif on_device:
+        t, p = D.as_device_csr(y_true, dev), D.as_device_csr(y_pred, dev)
+        if axis == 1:   # the rare direction: transpose with torch's sparse conversion, stays on the GPU
+            t = D.DeviceCSR.from_torch(t.to_torch(torch.int64).t().to_sparse_csr(), dev)
+            p = D.DeviceCSR.from_torch(p.to_torch(torch.int64).t().to_sparse_csr(), dev)
+        if p.data.dtype != t.data.dtype:
+            p = D.DeviceCSR(p.indptr, p.indices, p.data.to(t.data.dtype), p.shape, p.max_row_nnz, p.min_row_nnz)
+        stats = confusion_csr_device(t, p)
+        home = dev
+        is_torch = True
     else:
         if axis == 1:
             y_true, y_pred = y_true.T.tocsr(), y_pred.T.tocsr()
@@ -158,7 +173,9 @@ def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
 
     # dtype=None: CSR results take y_true's dtype (confusion_matrix.py:184, :214, :228); dense ones the dtype
     # of the summed product, i.e. numpy's promotion of the two inputs (:166, :193, :202)
-    if dense and is_torch:
+    if on_device:
+        default = t.data.dtype
+    elif dense and is_torch:
         default = torch.result_type(y_true, y_pred) if isinstance(y_pred, torch.Tensor) else y_true.dtype
     elif dense:
         default = np.result_type(y_true.dtype, y_pred.dtype if hasattr(y_pred, "dtype") else np.float64)
@@ -212,7 +229,7 @@ def calculate_confusion_matrix(y_true: Matrix, y_pred: Matrix, normalize: bool =
     ``-tp - fp - fn + (1 if normalize else n or m)`` (:397)."""
     stats, back = _column_stats(y_true, y_pred, axis)
     tp, fp, fn = (back(stats[i], dtype) for i in range(3))
-    n, m = y_true.shape
+    n, m = tuple(y_true.shape)
     if normalize:
         tp, fp, fn = tp / n, fp / n, fn / n
     if skip_tn:

@@ -76,7 +76,8 @@ struct SweepParams {
     int greedy;
     int skip_tn;
     int n_waves;
-    int validate; // concurrent mode: re-read the records of the labels a row is about to change
+    int validate; // concurrent mode: 0 = none, 1 = re-read the records of the labels a row is about to
+                  // change, 2 = commit them with returning atomics and compare (the default)
     unsigned long long *changed;
     unsigned long long *stamps; // diagnostic builds only (-DXC_STAMPS): per-phase cycle sums
     const double *ctrl;         // optional device-side loop control (XC_CTRL_*): stop flag and wave count
@@ -133,7 +134,9 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int p = lane + XC_WAVE * c;
-        const int pc = p < r ? p : r - 1;
+        // an empty row (refused by the host wrappers, but never trusted here) must not read before
+        // the row's first entry
+        const int pc = p < r ? p : (r > 0 ? r - 1 : 0);
         // read-once streams: non-temporal, so they do not evict the {tp, fp} records
         // (the gather table) from the XCD's L2
         if (PACKED) {
@@ -322,8 +325,21 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // same label), the row is re-scored on the fresh records.  Two rows in
         // flight that both want the same label are thereby serialised like in the
         // sequential sweep; rows that change nothing pay nothing.
-        bool in_new[CH];
+        // Commit protocol (concurrent mode, P.validate == 2, the default): a row that decides to CHANGE
+        // its prediction pushes the deltas of the labels it adds or drops at once, with RETURNING
+        // atomics, and compares what they return with the record values it scored on.  Equal: nobody
+        // touched those labels between this row's gather and its commit -- the commit is exactly what
+        // the sequential sweep would have done.  Different: another row in flight changed the same label
+        // first; this row's prediction in memory is now `in_new`, and it is simply processed again on
+        // fresh records (its own contribution removed in registers as always).  Two rows that want the
+        // same label are thereby serialised whatever their timing -- the validate-then-commit form
+        // below leaves the atomics' flight time (~1 us) as a window in which both still take it.
+        bool in_new[CH], in_cur[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) in_cur[c] = in_old[c];
+        int n_cur = n_old;
         bool row_changed = false;
+        const bool commit_mode = !EXACT && !greedy && P.validate == 2;
         const int kk = r < k ? r : k;
         for (int attempt = 0;; ++attempt) {
         // ---- gains (block_coordinate.py:248-282) ----
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                 double fpc = SHADOW ? (double)rec32[c].y : rec64[c].y;
                 double scc = sc[c];
                 // statistics without this row (:243-246, done in registers)
-                if (in_old[c]) {
+                if (in_cur[c]) {
                     tpc -= ed;
                     fpc -= omd;
                 }
@@ -391,8 +407,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // prediction that does not hold exactly k of the row's entries, goes to
         // the exact path below.
 #pragma unroll
-        for (int c = 0; c < CH; ++c) in_new[c] = in_old[c];
-        bool exact_path = (n_old != kk);
+        for (int c = 0; c < CH; ++c) in_new[c] = in_cur[c];
+        bool exact_path = (n_cur != kk);
         if (!exact_path) {
             for (int it = 0; it <= kk; ++it) {
                 unsigned long long lmin = ~0ull, lmax = 0ull;
@@ -472,9 +488,50 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // of the statistics (:290-293 minus :243-246) to memory ----
         bool any_change = false;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_old[c]);
+        for (int c = 0; c < CH; ++c) any_change = any_change || (in_new[c] != in_cur[c]);
         row_changed = __ballot(any_change) != 0ull;
-        if (EXACT || greedy || !P.validate || !row_changed || attempt >= XC_MAX_RETRY) break;
+        if (commit_mode) {
+            if (!row_changed) break; // nothing (more) to change: memory holds `in_cur`
+            bool conflict = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (in_new[c] != in_cur[c]) {
+                    const double sgn = in_new[c] ? 1.0 : -1.0;
+                    const double ed = (double)cur.eta[c];
+                    const double omd = (double)((T)1 - cur.eta[c]);
+                    if (hot_on && cur.hot[c] != 0) { // summed per workgroup, published by flush_hot
+                        (void)__hip_atomic_fetch_add(&s_hot[cur.hot[c]][0], (float)(sgn * ed), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_add(&s_hot[cur.hot[c]][1], (float)(sgn * omd), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (SHADOW) {
+                        float *sh = P.shadow + (int64_t)cur.idx[c] * 2;
+                        const float was_tp = atomic_add_ret_f32(sh + 0, (float)(sgn * ed));
+                        const float was_fp = atomic_add_ret_f32(sh + 1, (float)(sgn * omd));
+                        conflict = conflict || was_tp != rec32[c].x || was_fp != rec32[c].y;
+                        if (!P.acc) { // the float64 records are read again before a commit kernel rewrites them
+                            atomic_add_f64(P.tpfp + (int64_t)cur.idx[c] * 2, sgn * ed);
+                            atomic_add_f64(P.tpfp + (int64_t)cur.idx[c] * 2 + 1, sgn * omd);
+                        }
+                    } else {
+                        double *st = P.tpfp + (int64_t)cur.idx[c] * 2;
+                        const double was_tp = atomic_add_ret_f64(st + 0, sgn * ed);
+                        const double was_fp = atomic_add_ret_f64(st + 1, sgn * omd);
+                        conflict = conflict || was_tp != rec64[c].x || was_fp != rec64[c].y;
+                        if (P.shadow) { // keep the float32 copy in step
+                            atomic_add_f32(P.shadow + (int64_t)cur.idx[c] * 2, (float)(sgn * ed));
+                            atomic_add_f32(P.shadow + (int64_t)cur.idx[c] * 2 + 1, (float)(sgn * omd));
+                        }
+                    }
+                }
+                in_cur[c] = in_new[c];
+            }
+            n_cur = kk;
+            if (__ballot(conflict) == 0ull || attempt >= XC_MAX_RETRY) break;
+            // both of this row's atomics on a label have returned, i.e. have been performed at the
+            // memory side (and dropped the line from this XCD's L2): the gather below sees them
+        } else {
+        if (EXACT || greedy || P.validate != 1 || !row_changed || attempt >= XC_MAX_RETRY) break;
         // first only the records of the labels this row adds or drops (2-3 of its ~50
         // candidates: inactive lanes issue no request) ...
         bool moved = false;
@@ -493,6 +550,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             }
         }
         if (__ballot(moved) == 0ull) break;
+        }
         // ... and only after a conflict every candidate's record, to score the row again
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -504,6 +562,12 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                     double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
         }
         } // retry
+        if (commit_mode) { // in_new == in_cur == what memory holds; did the row end where it started?
+            bool differs = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) differs = differs || (in_new[c] != in_old[c]);
+            row_changed = __ballot(differs) != 0ull;
+        }
         XC_STAMP(3); // top-k
         // The from-scratch recompute of the sweep boundary (block_coordinate.py:465-467:
         // tp / fp of the new prediction summed over ALL rows) is accumulated row by row
@@ -570,7 +634,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                             atomic_add_f64(st + 0, ed);
                             atomic_add_f64(st + 1, omd);
                         }
-                    } else if (in_new[c] != in_old[c]) {
+                    } else if (!commit_mode && in_new[c] != in_old[c]) {
                         const double sgn = in_new[c] ? 1.0 : -1.0;
                         // a sweep that gathers the shadow AND accumulates the boundary's from-scratch
                         // statistics never reads the float64 records before the commit kernel
@@ -875,7 +939,7 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
 // one-shot HIP events recorded tightly around the NEXT sweep launch (xc_bca_time_next_sweep)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static int g_validate = 1;                           // xc_bca_set_validation
+static int g_validate = 2;                           // xc_bca_set_validation: 2 = commit protocol
 
 template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
 static void launch_sweep_one(const SweepParams<T> &P, hipStream_t st) {
@@ -1160,8 +1224,8 @@ int xc_bca_time_next_sweep(void *start, void *stop) {
     return XC_OK;
 }
 
-int xc_bca_set_validation(int on) {
-    xc::g_validate = on ? 1 : 0;
+int xc_bca_set_validation(int mode) {
+    xc::g_validate = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     return XC_OK;
 }
 

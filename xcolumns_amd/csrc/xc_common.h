@@ -40,6 +40,15 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Returning forms (`global_atomic_add_f32/f64 ... sc0`): the value the memory held before this add.
+__device__ __forceinline__ float atomic_add_ret_f32(float *p, float v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double atomic_add_ret_f64(double *p, double v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- top-k selection key ---------------------------------------------------
 // Order: larger gain first; equal gains -> lower candidate position (= lower
 // column id in a sorted row); NaN gains last (numpy sorts NaN last in -gains).

@@ -20,6 +20,8 @@ import torch
 import torch.distributed as dist
 from scipy.sparse import csr_matrix
 
+from . import _lib
+
 
 class TorchComm:
     """Thin view of a torch.distributed process group: sum all-reduce in place."""
@@ -30,12 +32,42 @@ class TorchComm:
         self.world = dist.get_world_size(group)
         self.bytes_reduced = 0
         self.calls = 0
+        self._timed = None   # list of (start, stop) event pairs while start_timing() is in effect
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        timed = self._timed is not None and t.is_cuda
+        if timed:
+            # on the stream the kernels run on: the collective's own stream is ordered behind `e0` and
+            # this stream waits for the collective before `e1`, so the span is the all-reduce as the
+            # sweep loop pays for it
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if timed:
+            e1.record()
+            self._timed.append((e0, e1))
         self.bytes_reduced += t.numel() * t.element_size()
         self.calls += 1
+        return t
+
+    def start_timing(self) -> None:
+        """bench.py: time every all-reduce of GPU tensors from here on with an event pair."""
+        self._timed = []
+
+    def stop_timing(self) -> float:
+        """Total milliseconds of the all-reduces since start_timing() (synchronises)."""
+        pairs, self._timed = self._timed or [], None
+        if not pairs:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in pairs))
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        """Control-plane reduction (argument checks that every rank must agree on); not counted
+        as data-path traffic."""
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
 
@@ -103,15 +135,33 @@ def predict_bca_csr_sharded(
     n_local, m = y_proba_shard.shape
     counts = torch.zeros(comm.world, dtype=torch.int64)
     counts[comm.rank] = n_local
+    counts_dev = counts.device
     if engine_factory is None:
         from . import _device as D
         dev = D.require_gpu()
         counts = counts.to(dev)
+        counts_dev = dev
     comm.all_reduce(counts)
     counts = counts.cpu().numpy()
     lo = int(counts[:comm.rank].sum())
     hi = lo + n_local
     n_total = int(counts.sum())
+    # The checks _bc_csr applies to the whole matrix, on the shards: the verdict is all-reduced so
+    # that every rank raises together instead of one rank leaving the others in a collective.
+    row_nnz = np.diff(y_proba_shard.indptr)
+    shortest = int(row_nnz.min()) if n_local > 0 else (1 << 30)
+    verdict = torch.tensor([-shortest, int(row_nnz.max()) if n_local > 0 else 0], dtype=torch.int64,
+                           device=counts_dev)
+    comm.all_reduce_max(verdict)
+    shortest, longest = -int(verdict[0].item()), int(verdict[1].item())
+    if k < 1 or k > _lib.XC_MAX_K:
+        raise ValueError(f"k must be in 1..{_lib.XC_MAX_K} for sparse y_proba on the GPU, got {k}")
+    if n_total > 0 and shortest < k:
+        raise ValueError(
+            f"every row of a sparse y_proba must store at least k={k} entries on the GPU path "
+            f"(shortest row over all ranks has {shortest})")
+    if longest > _lib.XC_MAX_ROW_NNZ:
+        raise ValueError(f"a row stores {longest} entries, the GPU path handles at most {_lib.XC_MAX_ROW_NNZ}")
 
     gain_spec = resolve_metric(binary_metric_func, metric_kwargs)
     utility_spec = resolve_metric(binary_metric_func, None)

@@ -27,10 +27,20 @@ CSRMatrixAsTuple = Tuple[np.ndarray, np.ndarray, np.ndarray]  # (data, indices, 
 
 
 def is_dense(x) -> bool:
-    """ndarray or torch tensor."""
-    return isinstance(x, _DENSE_TYPES)
+    """ndarray or (strided) torch tensor."""
+    if isinstance(x, torch.Tensor):
+        return x.layout == torch.strided
+    return isinstance(x, np.ndarray)
+
+
+def is_sparse(x) -> bool:
+    """csr_matrix, or a sparse matrix already resident in HBM: xcolumns_amd.DeviceCSR or a torch
+    ``sparse_csr`` tensor (this build's extension of the reference's type seam, types.py:10-23)."""
+    from ._device import is_device_sparse
+
+    return isinstance(x, csr_matrix) or is_device_sparse(x)
 
 
 def is_matrix(x) -> bool:
-    """Any of the three input kinds the path accepts."""
-    return isinstance(x, _MATRIX_TYPES)
+    """Any of the input kinds the path accepts."""
+    return is_dense(x) or is_sparse(x)

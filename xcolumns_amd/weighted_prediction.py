@@ -106,12 +106,24 @@ def _predict_weighted_per_instance_csr(y_proba: csr_matrix, k, th=0.0, a=None, b
                                        keep_scores=False, dtype=None) -> csr_matrix:
     """weighted_prediction.py:63-88 -> numba_csr_functions.py:585-655."""
     dev = D.require_gpu()
-    n, m = y_proba.shape
-    csr = D.DeviceCSR.from_scipy(y_proba, dev)
+    n, m = tuple(y_proba.shape)
+    csr = D.as_device_csr(y_proba, dev)
     tdt = csr.data.dtype
     # weights are cast to y_proba's dtype (:72-75)
     a_d = None if a is None else D.to_device(a, dtype=tdt, device=dev)
     b_d = None if b is None else D.to_device(b, dtype=tdt, device=dev)
+    if not isinstance(y_proba, csr_matrix):
+        # resident in HBM (DeviceCSR / torch sparse_csr): the prediction stays there, same kind of object
+        out_dt = tdt if dtype is None else D.torch_dtype(dtype)
+        if k > 0:
+            idx, dat, _ = topk_csr_device(csr, k, a_d, b_d, keep_scores)
+            return D.fixed_width_prediction(y_proba, idx, k, n, m, values=dat.to(out_dt))
+        indptr, idx = threshold_csr_device(csr, th, a_d, b_d)
+        ones = torch.ones(idx.numel(), dtype=out_dt, device=dev)
+        if isinstance(y_proba, D.DeviceCSR):
+            return D.DeviceCSR.from_parts(indptr, idx, ones, (n, m), dev, check=False)
+        idt = y_proba.crow_indices().dtype
+        return torch.sparse_csr_tensor(indptr.to(idt), idx.to(idt), ones, size=(n, m))
     if k > 0:
         idx, dat, _ = topk_csr_device(csr, k, a_d, b_d, keep_scores)
         out_indptr = (np.arange(n + 1, dtype=np.int64) * k).astype(y_proba.indptr.dtype)
