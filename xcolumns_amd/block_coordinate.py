@@ -17,6 +17,9 @@ reference's signature so call sites stay source-compatible):
 ``bca_waves``      number of wavefronts that walk the visiting order concurrently
                    (1 = the reference's exact sequential sweep; default: the
                    staleness-budget policy, :class:`WavePolicy`).
+``bca_parity``     "per_sweep" (default): every sweep's utility within 1e-5 of the sequential reference;
+                   "final": wider sweeps, the bar holds for the utility after the last sweep
+                   (:class:`WavePolicy`; env XCOLUMNS_BCA_PARITY).
 ``bca_diagnostics`` True: ``meta`` also carries "wavefronts" and "rows_changed" per sweep
                    (by default ``meta`` has exactly the reference's keys).
 ``order_backend``  "numpy" (default: the reference's RNG stream, generated on the
@@ -56,37 +59,75 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 # ---------------------------------------------------------------------------
 # how many wavefronts walk the visiting order concurrently
 # ---------------------------------------------------------------------------
-# The reference's sweep is sequential; here W rows are in flight at once and miss
-# each other's update.  Measured on MI355X (DESIGN.md "staleness"): the per-sweep
-# utility differs from the sequential sweep's by about
-#     c * (rows that change in the sweep / n) * (W / n),   c ~ 0.3e-2 .. 1e-2
-# (with the kernel's optimistic validation of changed rows; twice that without),
-# and the difference heals in the following sweeps.  The default keeps that
-# product below XCOLUMNS_BCA_STALE_BUDGET for every sweep, using the previous
-# sweep's number of changed rows (n/2 before the first): W grows as the
-# optimisation converges, so late sweeps use the whole GPU.  The constant was measured at the
-# benchmark's budget k = 5; a changing row moves more labels the larger k is and the trajectories
-# then settle in different, nearly equivalent optima (k = 64, n = 6000: 1.6e-4 in sweep 1 at the
-# k = 5 width, 1-4e-5 left after 8 sweeps at 1/13 of it), so the budget is scaled by (5 / k)^1.5.
-_STALE_BUDGET = float(os.environ.get("XCOLUMNS_BCA_STALE_BUDGET", "4e-3"))
+# The reference's sweep is sequential; here W rows are in flight at once.  A row that CHANGES its
+# prediction is serialised against the other rows in flight by the kernel's commit protocol
+# (csrc/xc_bca.hip); what is left is a row that was scored on a record another row changed a moment
+# later and kept its (by then slightly wrong) decision.  Two rows interact when one changes a label the
+# other holds as a candidate, so the natural measure of concurrency is rows in flight per LABEL, W / m,
+# not per row.  Measured on MI355X, |utility - sequential oracle| of a sweep from the top-k start
+# (profiles/r02_policy_study.txt; macro-F1, k = 5, 50 entries per row):
+#     uniform label popularity:  ~2.5e-4 * (rows changed / n) * (W / m)     (n = 20 K .. 1 M)
+#     Zipf(1) popularity, sweep 1 (every row changes, mostly into tail labels that hold one or two
+#     rows): ~2e-3 * (W / m); from sweep 2 on below the uniform figure
+# and the difference heals in the following sweeps.  The reference itself moves by 2.5e-6 (uniform) /
+# 3.3e-5 (Zipf) standard deviation in sweep 1 when only its visiting order (`seed`) changes.
+#
+# bca_parity = "per_sweep" (default): EVERY sweep within north_star's 1e-5 of the sequential reference --
+#     W_j = BETA * m * (50 / entries per row) * (5 / k)^1.5 * n / (2 * rows changed in sweep j-1)
+#     (half of the rows assumed before sweep 1), an eighth of it for the first sweep when the label
+#     popularity is skewed (hot labels present); converged sweeps use the whole GPU.
+# bca_parity = "final": four times wider -- the utility after the LAST sweep is what is held to 1e-5
+#     (intermediate sweeps of a top-k start stay within ~5e-5), for callers that only use the result.
+# A changing row moves more labels the larger k is and the trajectories then settle in different, nearly
+# equivalent optima (k = 64, n = 6000: 1.6e-4 in sweep 1 at the k = 5 width), hence (5 / k)^1.5.
+_BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.04"))
+_SKEWED_FIRST_SWEEP = 0.125
+_FINAL_PARITY_FACTOR = 4.0
+_STALE_BUDGET = float(os.environ["XCOLUMNS_BCA_STALE_BUDGET"]) if "XCOLUMNS_BCA_STALE_BUDGET" in os.environ else None
 _MIN_WAVES = 1
+
+
+def default_parity() -> str:
+    p = os.environ.get("XCOLUMNS_BCA_PARITY", "per_sweep")
+    if p not in ("per_sweep", "final"):
+        raise ValueError("XCOLUMNS_BCA_PARITY / bca_parity must be 'per_sweep' or 'final'")
+    return p
 
 
 class WavePolicy:
     """Number of concurrent wavefronts for the next sweep."""
 
     def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None,
-                 world: int = 1, k: int = 5, first_changed: float = 0.5):
-        """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows
-        (the changed-row count fed to :meth:`next` is the global one); `k`: labels per row;
-        `first_changed`: expected share of rows the first sweep changes (about half from the top-k
-        prediction, all of them from a random or foreign one)."""
+                 world: int = 1, k: int = 5, first_changed: float = 0.5, m: Optional[int] = None,
+                 row_nnz: float = 50.0, skewed: bool = False, parity: Optional[str] = None, scale: float = 1.0):
+        """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows (the changed-row
+        count fed to :meth:`next` is the global one); `k`: labels per row; `first_changed`: expected share
+        of rows the first sweep changes (about half from the top-k prediction, all of them from a random
+        or foreign one); `m`: labels, `row_nnz`: mean stored entries per row, `skewed`: hot labels present
+        (first sweep narrower); `parity`: "per_sweep" | "final"; `scale`: extra factor on the width.
+        `budget` (or XCOLUMNS_BCA_STALE_BUDGET) selects the round-1 rule instead: W = budget * n^2 / changed."""
         self.first_changed = float(first_changed)
         self.world = max(1, int(world))
         env = os.environ.get("XCOLUMNS_BCA_WAVES")
         self.fixed = int(fixed) if fixed else (int(env) if env else None)
         self.n = max(1, int(n_order))
-        self.budget = (_STALE_BUDGET if budget is None else float(budget)) * min(1.0, 5.0 / max(1, int(k))) ** 1.5
+        self.parity = default_parity() if parity is None else parity
+        if self.parity not in ("per_sweep", "final"):
+            raise ValueError("bca_parity must be 'per_sweep' or 'final'")
+        k_scale = min(1.0, 5.0 / max(1, int(k))) ** 1.5
+        if budget is None and _STALE_BUDGET is not None:
+            budget = _STALE_BUDGET
+        if budget is not None or m is None:
+            b = 8e-3 if budget is None else float(budget)
+            self.num = b * k_scale * float(self.n) * float(self.n)
+            self.first_factor = 1.0
+        else:
+            width = _BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
+            if self.parity == "final":
+                width *= _FINAL_PARITY_FACTOR
+            self.num = width * self.n / 2.0
+            self.first_factor = _SKEWED_FIRST_SWEEP if skewed else 1.0
+        self.budget = self.num / (float(self.n) * float(self.n))   # the same rule as a share of n (diagnostics)
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
 
@@ -97,20 +138,21 @@ class WavePolicy:
         if self.fixed:
             return max(1, min(self.fixed, self.n))
         if greedy:
-            return int(max(1, min(self.cap, self.n, self.budget * self.n / 32)))
+            return int(max(1, min(self.cap, self.n, self.num / self.n / 32)))
         # sharded rows: the other ranks' updates are invisible within a sweep whatever W is (DESIGN.md
-        # section 7), but this rank's own rows still follow the budget, on its share of the changes
-        changed = self.n * self.first_changed if changed_prev is None else max(1.0, changed_prev / self.world)
-        want = int(self.budget * self.n * self.n / changed)
+        # section 7), but this rank's own rows still follow the rule, on its share of the changes
+        if changed_prev is None:
+            want = int(self.num * self.first_factor / (self.n * self.first_changed))
+        else:
+            want = int(self.num / max(1.0, changed_prev / self.world))
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
-
 
     def device_params(self):
         """(policy_num, world, min_waves, max_waves, fixed_waves) for xc_bca_pipeline_begin: the same
         rule as :meth:`next`, evaluated by the boundary kernel."""
         max_w = int(max(1, min(self.cap, self.n)))
         fixed = int(max(1, min(self.fixed, self.n))) if self.fixed else 0
-        return self.budget * self.n * self.n, self.world, _MIN_WAVES, max_w, fixed
+        return self.num, self.world, _MIN_WAVES, max_w, fixed
 
     @property
     def sequential(self) -> bool:
@@ -193,7 +235,11 @@ class BcaCsrEngine:
         self.acc = torch.zeros(2 * m + 1, dtype=torch.float64, device=dev)
         # sharded rows: exchanges of the ranks' changes per sweep (1 = only the all-reduce of the
         # from-scratch statistics at the sweep boundary, the north-star scheme)
-        self.exchanges = max(1, int(os.environ.get("XCOLUMNS_BCA_EXCHANGES", "1")))
+        # sweep), S > 1 = S - 1 more all-reduces of the float32 records inside the sweep, "auto" = several in
+        # the sweeps that change many rows and 1 once converged (distributed.exchanges_for_sweep)
+        env_x = os.environ.get("XCOLUMNS_BCA_EXCHANGES", "auto")
+        self.exchanges = "auto" if env_x == "auto" else max(1, int(env_x))
+        self._changed_known = None   # rows changed (all ranks) in the last sweep whose result the host has read
         self._acc_filled = False    # did the last sweep leave the new prediction's statistics in acc
         self._changed_last = 0
         self.partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=dev)
@@ -354,6 +400,7 @@ class BcaCsrEngine:
             self._pipe_seq = 0.0      # grows by one per boundary over the engine's lifetime
             self._seq_of = {}
         num, world, min_w, max_w, fixed = policy.device_params()
+        self._changed_known = None
         self._pipe_max_waves = max(2, max_w)
         _lib.call("xc_bca_pipeline_begin", D.ptr(self._ctrl), float(old_utility_sum), float(tolerance), float(divisor),
                   int(bool(maximize)), float(num), int(world), int(min_w), int(max_w), int(fixed),
@@ -366,7 +413,14 @@ class BcaCsrEngine:
             self._repack()
         use_packed = self.packed is not None
         n = self.csr.n
-        segments = self.exchanges if (self.comm is not None and self.shadow is not None) else 1
+        segments = 1
+        if self.comm is not None and self.shadow is not None:
+            from .distributed import exchange_changes, exchanges_for_sweep
+            # the host runs one boundary behind the GPU: the newest changed-row count it has is sweep j - 2's
+            # (identical on every rank -- it comes out of the all-reduced statistics -- so all ranks agree)
+            segments = min(exchanges_for_sweep(self.exchanges, self._changed_known, self.n_total, self.comm.world), max(1, n))
+        self.exchanges_used = getattr(self, "exchanges_used", [])
+        self.exchanges_used.append(segments)
         if segments <= 1:
             _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), 0, n, int(use_packed),
                       int(self._pipe_max_waves), D.ptr(self._ctrl), D.stream())
@@ -386,11 +440,7 @@ class BcaCsrEngine:
                           bounds[s + 1] - bounds[s], int(use_packed), int(self._pipe_max_waves), D.ptr(self._ctrl),
                           D.stream())
                 if s < segments - 1:
-                    mine = self.shadow - self._snap
-                    everyone = mine.clone()
-                    self.comm.all_reduce(everyone)
-                    self.shadow += everyone - mine
-                    self._snap.copy_(self.shadow)
+                    exchange_changes(self.comm, self.shadow, self._snap)
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
         slot = j % _lib.XC_CTRL_RING_SLOTS
@@ -410,6 +460,7 @@ class BcaCsrEngine:
         total, changed, waves, flag = r[o], r[o + 1], r[o + 2], r[o + 3]
         if flag != 2.0:
             self._changed_last = int(round(changed))
+            self._changed_known = self._changed_last
         return total, int(round(changed)), int(waves), int(flag)
 
     def close(self):
@@ -522,7 +573,15 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
         log_info("    Doing block coordinate optimization steps ...", verbose)
         eng.reset_changed()
         n_waves = policy.next(changed_prev, greedy=True) if greedy else policy.next(changed_prev)
-        eng.sweep(order, n_order, n_waves, greedy=greedy)
+        n_seg = 1
+        if not greedy and getattr(eng, "supports_segments", False) and getattr(eng, "comm", None) is not None:
+            from .distributed import exchanges_for_sweep
+            n_seg = exchanges_for_sweep(getattr(eng, "exchanges", 1), changed_prev, n_u, eng.comm.world)
+        if n_seg > 1:
+            eng.sweep_segments(order, n_order, n_waves, n_seg)   # S - 1 mid-sweep exchanges between row shards
+        else:
+            eng.sweep(order, n_order, n_waves, greedy=greedy)
+        meta.setdefault("exchanges", []).append(n_seg)
         if greedy:
             eng.sync_column_sums()
         new_utility_sum = eng.recompute_utility_sum(n_u)
@@ -605,7 +664,8 @@ def _initial_csr_indices(y_proba, init_y_pred, k: int, seed):
 
 
 def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
-            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves, order_backend):
+            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves, order_backend,
+            bca_parity=None):
     """Sparse y_proba: a csr_matrix in host memory (uploaded here, result downloaded) or a matrix already
     resident in HBM -- DeviceCSR or torch sparse_csr tensor -- in which case nothing crosses PCIe but the
     visiting orders and the per-sweep utility."""
@@ -650,7 +710,8 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
     # a random / foreign / greedy start changes every row in sweep 1 and keeps many rows moving for several
     # sweeps (measured 5e-5 .. 1.2e-4 at the top-k width): half the budget for the whole run
     policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if init_idx is None else 1.0,
-                        budget=None if init_idx is None else _STALE_BUDGET / 2)
+                        m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.hot_labels is not None,
+                        parity=bca_parity, scale=1.0 if init_idx is None else 0.5)
     run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                    policy, verbose, meta)
 
@@ -702,7 +763,7 @@ _DENSE_MAX_LABELS = 8192      # xc_bca_sweep_dense_concurrent keeps <= 8 labels 
 
 
 def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance, init_y_pred,
-              max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend, bca_waves=None):
+              max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend, bca_waves=None, bca_parity=None):
     n_rows, m = y_proba.shape
     if k < 0:
         raise ValueError("k must be >= 0")
@@ -741,9 +802,12 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
     # workgroups the GPU holds; bca_waves=1 is the reference's sequential sweep
     if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
         bca_waves = 1   # macro precision is chaotic under any concurrency (see _bc_csr): sequential by default
-    policy = WavePolicy(n_u, fixed=bca_waves, k=max(1, k),
-                        first_changed=0.5 if (isinstance(init_y_pred, str) and init_y_pred == "top") else 1.0,
-                        budget=None if (isinstance(init_y_pred, str) and init_y_pred == "top") else _STALE_BUDGET / 2)
+    from_top = isinstance(init_y_pred, str) and init_y_pred == "top"
+    # the dense sweep keeps the round-1 rule (validate-then-commit, no commit protocol): rows in flight as
+    # a share of n, W = 4e-3 * n^2 / rows changed, half of it for a random or foreign start
+    policy = WavePolicy(n_u, fixed=bca_waves, k=max(1, k), first_changed=0.5 if from_top else 1.0,
+                        budget=(4e-3 if from_top else 2e-3) * (_FINAL_PARITY_FACTOR if bca_parity == "final" else 1.0),
+                        parity=bca_parity)
     max_blocks = max(1, policy.cap // _DENSE_BLOCK_WAVES)
     changed = torch.zeros(1, dtype=torch.int64, device=dev)
     changed_prev = None
@@ -860,21 +924,25 @@ def predict_using_bc_with_0approx(
     n_u = n if normalize_conf_matrix else 1   # :403-405 (also the length of the visiting order, :414)
 
     bca_waves = kwargs.pop("bca_waves", None)
+    bca_parity = kwargs.pop("bca_parity", None)
+    if bca_parity not in (None, "per_sweep", "final"):
+        raise ValueError("bca_parity must be 'per_sweep' or 'final'")
     bca_diagnostics = kwargs.pop("bca_diagnostics", False)
     order_backend = kwargs.pop("order_backend", os.environ.get("XCOLUMNS_ORDER_BACKEND", "numpy"))
 
     if is_sparse(y_proba):
         y_pred = _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                          init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves,
-                         order_backend)
+                         order_backend, bca_parity)
     else:
         y_pred = _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend,
-                           bca_waves)
+                           bca_waves, bca_parity)
 
     if not bca_diagnostics:
         meta.pop("wavefronts", None)
         meta.pop("rows_changed", None)
+        meta.pop("exchanges", None)
     if return_meta:
         meta["time"] = time() - meta["time"]
         return y_pred, meta

@@ -71,6 +71,52 @@ class TorchComm:
         return t
 
 
+def exchange_changes(comm: "TorchComm", records: torch.Tensor, snapshot: torch.Tensor) -> None:
+    """Mid-sweep exchange between row shards: every rank publishes what ITS rows changed in the
+    replicated per-label `records` since `snapshot` was taken and takes in the other ranks' changes
+    (one all-reduce of the difference), in place; `snapshot` is left equal to the merged records.
+    Works on any device (the GPU engine passes its float32 records, the CPU tests a float64 table)."""
+    mine = records - snapshot
+    everyone = mine.clone()
+    comm.all_reduce(everyone)
+    records += everyone - mine
+    snapshot.copy_(records)
+
+
+# Cross-rank staleness: within a sweep a rank does not see what the other ranks' rows change -- the sweep
+# is Gauss-Seidel inside a shard and Jacobi across shards.  Measured with the sequential checker engine
+# on 2 and 8 gloo ranks (tests/studies/shard_exchange_study.py, profiles/r02_shard_exchange_study.txt;
+# macro-F1, k = 5, |utility - sequential reference| per sweep):
+#   * ONE exchange per sweep (only the boundary all-reduce, north_star's scheme) does not merely lag: with
+#     8 shards every rank corrects the same imbalance of a label with its own rows, the corrections add up
+#     8-fold, and on uniform label popularity the utility FALLS from sweep to sweep (20 K x 6 K:
+#     4.9e-3, 6.4e-3, 8.6e-3, ... ; 40 K x 2.5 K: 1e-3 -> 3e-3); 2 shards converge, slowly (x0.7 / sweep).
+#   * S exchanges per sweep contract: 8 shards, S = 2: x0.45 per sweep; S = 4: x0.3 (1.1e-4, 3.2e-5, 8.3e-6,
+#     2.7e-6, 8.9e-7, 2.2e-7); S = 8: 4.9e-5, 1.3e-5, 3.3e-6, 8.2e-7, ...  The first-sweep difference is about
+#     4e-4 / S (uniform) .. 6e-3 / S (Zipf, where every row changes) and heals in the following sweeps.
+# "auto": as many exchanges as the sweep is expected to change rows (up to EXCHANGES_MAX), never fewer than
+# the number that keeps the iteration contracting for the shard count.
+EXCHANGES_MAX = 8
+_EXCHANGE_PER_CHANGED_SHARE = 16.0   # S = ceil(this * share of rows the sweep is expected to change)
+
+
+def min_exchanges(world: int) -> int:
+    """Fewest exchanges per sweep at which the sharded iteration contracts towards the sequential one."""
+    return 1 if world <= 1 else (2 if world <= 4 else 4)
+
+
+def exchanges_for_sweep(setting, changed_rows: Optional[float], n_total: int, world: int) -> int:
+    """Exchanges of a sweep: `setting` = an integer (fixed) or "auto" (from the number of rows the last KNOWN
+    sweep changed over all ranks; None before any is known = half of the rows)."""
+    if world <= 1:
+        return 1
+    if setting not in (None, "auto", 0):
+        return max(1, int(setting))
+    share = 0.5 if changed_rows is None else float(changed_rows) / max(1, n_total)
+    want = int(-(-_EXCHANGE_PER_CHANGED_SHARE * share // 1))
+    return int(max(min_exchanges(world), min(EXCHANGES_MAX, want)))
+
+
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row block of `rank`: sizes differ by at most one row."""
     base, rem = divmod(n, world)
@@ -121,10 +167,11 @@ def predict_bca_csr_sharded(
     row ids, restricted to the rank's block (:func:`local_order`).
     `engine_factory(csr_shard, k, gain_spec, utility_spec, maximize, skip_tn, n_total,
     comm)` builds the per-rank engine; the default is the GPU engine.
-    `bca_exchanges` (default 1, env XCOLUMNS_BCA_EXCHANGES): how often per sweep the ranks
+    `bca_exchanges` (default "auto", env XCOLUMNS_BCA_EXCHANGES): how often per sweep the ranks
     exchange what their rows changed; 1 = only the all-reduce of the from-scratch statistics
-    at the sweep boundary, S > 1 = S - 1 more all-reduces of the float32 records (8 bytes per
-    label) inside the sweep, which cuts the cross-rank staleness about S-fold."""
+    at the sweep boundary (north_star's scheme), S > 1 = S - 1 more all-reduces of the float32
+    records (8 bytes per label) inside the sweep, which cuts the cross-rank staleness about S-fold;
+    "auto" = :func:`exchanges_for_sweep`: several in the sweeps that change many rows, 1 afterwards."""
     from time import time
 
     from . import block_coordinate as bc
@@ -170,10 +217,11 @@ def predict_bca_csr_sharded(
         eng = bc.BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
                               n_total=n_total, comm=comm)
         if bca_exchanges:
-            eng.exchanges = max(1, int(bca_exchanges))
+            eng.exchanges = "auto" if bca_exchanges == "auto" else max(1, int(bca_exchanges))
         to_dev = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
     else:
         eng = engine_factory(y_proba_shard, k, gain_spec, utility_spec, maximize, skip_tn, n_total, comm)
+        eng.exchanges = "auto" if bca_exchanges in (None, "auto") else max(1, int(bca_exchanges))
         to_dev = lambda a: a  # noqa: E731
     eng.init_top()
 
@@ -187,10 +235,13 @@ def predict_bca_csr_sharded(
         return to_dev(local_order(order, lo, hi))
 
     meta = {"utilities": [], "iters": 0, "time": time()}
-    policy = (bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world, k=k) if engine_factory is None
-              else _FixedWaves(bca_waves or 1))
+    policy = (bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world, k=k, m=m,
+                            row_nnz=y_proba_shard.nnz / max(1, n_local), skewed=eng.hot_labels is not None)
+              if engine_factory is None else _FixedWaves(bca_waves or 1))
     bc.run_bca_sweeps(eng, next_order, n_local, n_total, m, metric_aggregation, maximize, tolerance, max_iters,
                       False, policy, verbose, meta)
+    if getattr(eng, "exchanges_used", None):
+        meta["exchanges"] = list(eng.exchanges_used)
     meta["time"] = time() - meta["time"]
     idx = eng.pred_idx.cpu().numpy() if isinstance(eng.pred_idx, torch.Tensor) else np.asarray(eng.pred_idx)
     out_indptr = (np.arange(n_local + 1, dtype=np.int64) * k).astype(y_proba_shard.indptr.dtype)
