@@ -185,6 +185,12 @@ int xc_bca_gather_pred_eta(int64_t n, const int32_t *indptr, const int32_t *indi
 int xc_bca_colsum_csr(int64_t nnz, const int32_t *indices, const void *data,
                       int dtype, double *colsum, void *stream);
 
+/* The packed stream straight from the per-label column sums (a gather of colsum[indices[p]] instead of
+ * a read of s_entry[p]): a run whose sweeps all read the packed stream then never builds s_entry. */
+int xc_bca_pack_rows_from_colsum(int64_t nnz, const int32_t *indices, const float *data,
+                                 const uint8_t *sel, const double *colsum, const uint8_t *hot_slot,
+                                 void *packed, void *stream);
+
 /* s_entry[p] = colsum[indices[p]] for every stored entry p. */
 int xc_bca_expand_colsum(int64_t nnz, const int32_t *indices, const double *colsum,
                          double *s_entry, void *stream);

@@ -1,0 +1,145 @@
+"""-m gpu tests of the round-2 API surface: sparse inputs already resident in HBM (DeviceCSR, torch sparse_csr),
+the visiting-order worker, RCCL through TorchComm, and bench.py starting its own ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(n=30000, m=4000, r=40, k=5, seed=3):
+    from xcolumns_amd.synthetic import make_csr
+    return make_csr(n, m, r, seed=seed, k=k), k
+
+
+def test_device_resident_inputs_top_k_and_confusion(oref):
+    """predict_top_k / predict_weighted_per_instance / calculate_confusion_matrix on a DeviceCSR and on a torch
+    sparse_csr tensor: same index sets as the host csr_matrix call (bit-exact vs the oracle), the result is the
+    same kind of object and stays on the GPU."""
+    from xcolumns_amd import DeviceCSR
+    from xcolumns_amd.confusion_matrix import calculate_confusion_matrix
+    from xcolumns_amd.weighted_prediction import predict_top_k, predict_weighted_per_instance
+
+    Y, k = _problem()
+    n, m = Y.shape
+    want = oref.predict_top_k(Y, k)
+    d = DeviceCSR.from_scipy(Y)
+    Pd = predict_top_k(d, k)
+    assert isinstance(Pd, DeviceCSR) and Pd.indices.is_cuda and Pd.shape == (n, m) and Pd.dtype == Y.dtype
+    assert np.array_equal(Pd.indices.cpu().numpy(), want.indices)
+    t = torch.sparse_csr_tensor(torch.from_numpy(Y.indptr.astype(np.int64)), torch.from_numpy(Y.indices.astype(np.int64)),
+                                torch.from_numpy(Y.data), size=Y.shape).cuda()
+    Pt = predict_top_k(t, k)
+    assert isinstance(Pt, torch.Tensor) and Pt.layout == torch.sparse_csr and Pt.is_cuda and tuple(Pt.shape) == (n, m)
+    assert Pt.col_indices().dtype == torch.int64 and np.array_equal(Pt.col_indices().cpu().numpy(), want.indices)
+    # weights + keep_scores
+    rng = np.random.default_rng(0)
+    a, b = rng.random(m).astype(np.float32) + 0.5, rng.random(m).astype(np.float32) * 0.1
+    Wh = predict_weighted_per_instance(Y, k, a=a, b=b, keep_scores=True)
+    Wd = predict_weighted_per_instance(d, k, a=a, b=b, keep_scores=True)
+    assert np.array_equal(Wd.indices.cpu().numpy(), Wh.indices) and np.array_equal(Wd.data.cpu().numpy(), Wh.data)
+    # k = 0: threshold
+    Th = predict_weighted_per_instance(Y, 0, th=0.3)
+    Td = predict_weighted_per_instance(d, 0, th=0.3)
+    assert np.array_equal(Td.indptr.cpu().numpy(), Th.indptr) and np.array_equal(Td.indices.cpu().numpy(), Th.indices)
+    # confusion matrix of device-resident matrices: torch vectors on the GPU, equal to the host call
+    Ch = calculate_confusion_matrix(Y, want, skip_tn=True, dtype=np.float64)
+    Cd = calculate_confusion_matrix(d, Pd, skip_tn=True, dtype=np.float64)
+    for h, g in zip(Ch, Cd):
+        assert isinstance(g, torch.Tensor) and g.is_cuda
+        np.testing.assert_allclose(g.cpu().numpy(), h, rtol=0, atol=1e-9)
+    Ct = calculate_confusion_matrix(t, Pt, skip_tn=True, dtype=np.float64)
+    np.testing.assert_allclose(Ct.tp.cpu().numpy(), Ch.tp, rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        calculate_confusion_matrix(d, want)          # mixing a device matrix with a host one is refused
+
+
+def test_device_resident_inputs_bca(oref):
+    """predict_optimizing_macro_f1_score_using_bc on DeviceCSR / torch sparse_csr: exact mode reproduces the
+    oracle's prediction, the default mode stays within the bar, init_y_pred of the same kind is updated in place."""
+    from xcolumns_amd import DeviceCSR
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+
+    Y, k = _problem(20000, 3000, 30)
+    n, m = Y.shape
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=5, max_iters=3, tolerance=-1.0)
+    d = DeviceCSR.from_scipy(Y)
+    Pe, me = f(d, k, seed=5, max_iters=3, tolerance=-1.0, return_meta=True, bca_waves=1)
+    assert isinstance(Pe, DeviceCSR) and np.array_equal(Pe.indices.cpu().numpy(), Po.indices)
+    assert np.allclose(me["utilities"], mo["utilities"], rtol=0, atol=1e-12)
+    t = d.to_torch(torch.int64)
+    Pt, mt = f(t, k, seed=5, max_iters=3, tolerance=-1.0, return_meta=True)
+    assert Pt.layout == torch.sparse_csr and Pt.is_cuda and (Pt.crow_indices().diff() == k).all()
+    assert np.abs(np.asarray(mt["utilities"]) - np.asarray(mo["utilities"])).max() < 1e-5
+    init = f(d, k, seed=1, max_iters=1, tolerance=-1.0)
+    out = f(d, k, seed=5, max_iters=2, tolerance=-1.0, init_y_pred=init)
+    assert out is init
+    with pytest.raises(ValueError):
+        f(DeviceCSR.from_scipy(Y[:, :]), k + 100)     # rows shorter than k are refused before any launch
+    with pytest.raises(ValueError):
+        DeviceCSR.from_parts(d.indptr, d.indices + m, d.data, d.shape)   # column ids out of range
+
+
+def test_order_worker_delivers_the_reference_stream():
+    """The visiting orders a worker thread prepares ahead (pinned buffer, side stream) are numpy's stream."""
+    from xcolumns_amd import _device as D
+    from xcolumns_amd.block_coordinate import _OrderSource
+
+    n = 120_000
+    dev = D.require_gpu()
+    src = _OrderSource(n, 13, True, "numpy", dev)
+    assert src._thread is not None
+    rng = np.random.default_rng(13)
+    ref = np.arange(n)
+    try:
+        for _ in range(6):
+            rng.shuffle(ref)
+            got = src.next()
+            torch.cuda.synchronize()
+            assert got.dtype == torch.int32 and got.is_cuda and np.array_equal(got.cpu().numpy(), ref.astype(np.int32))
+    finally:
+        src.close()
+    assert src._thread is None
+
+
+def test_rccl_all_reduce_through_torchcomm():
+    """backend "nccl" (= RCCL) with the one rank a one-GPU box allows: the collective the sharded sweep issues at
+    every boundary -- an in-place float64 sum over 2m + 1 values on the compute stream -- runs through RCCL."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29571')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from xcolumns_amd.distributed import TorchComm\n"
+        "c = TorchComm(); c.start_timing()\n"
+        "t = torch.arange(1000001, dtype=torch.float64, device='cuda'); c.all_reduce(t); ms = c.stop_timing()\n"
+        "assert dist.get_backend() == 'nccl' and float(t[-1]) == 1e6 and c.calls == 1 and c.bytes_reduced == 8 * 1000001\n"
+        "print('rccl ok', ms)\n"
+        "dist.destroy_process_group()\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run: the parent starts the ranks as children and relays
+    ONE JSON line (rehearsed with gloo on the one GPU: RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, XC_BENCH_BACKEND="gloo", XC_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2_100Kx30K",
+                          "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["value"] > 0
+    assert j["comm"]["world_size"] == 2 and j["comm"]["backend"] == "gloo" and j["comm"]["all_reduce_bytes_per_sweep"] > 0
+    assert j["config"]["rows_total"] == 200_000 and j["strong_scaling"]["rows_total"] == 100_000
+    assert len(j["roofline"]["frac_by_sweep"]) == 3 and 0 < j["roofline"]["frac"] < 1

@@ -116,11 +116,7 @@ def test_public_surface_of_the_reference_is_present():
 
 def test_order_stream_is_the_reference_stream():
     """block_coordinate.py:413-419: one Generator, cumulative in-place shuffles."""
-    src = bc._OrderSource.__new__(bc._OrderSource)
-    src.n, src.shuffle, src.backend, src.dev = 10, True, "numpy", "cpu"
-    src.rng = np.random.default_rng(42)
-    src.order = np.arange(10)
-    src.gen = None
+    src = bc._OrderSource(10, 42, True, "numpy", "cpu", prefetch=False)
     rng = np.random.default_rng(42)
     ref = np.arange(10)
     for _ in range(3):
@@ -238,3 +234,55 @@ def test_io_loaders_match_the_reference(tmp_path):
     a = xio.load_cache_npz_file(base, loader)
     b = xio.load_cache_npz_file(base, loader)
     assert len(calls) == 1 and (a != b).nnz == 0
+
+
+def test_engine_releases_its_plan_exactly_once(monkeypatch):
+    """BcaCsrEngine.close() / __del__ (one definition): the C-side plan is destroyed once, whether the engine
+    is closed explicitly, twice, or only garbage-collected -- it leaked when a second __del__ shadowed the first."""
+    calls = []
+
+    class FakeLib:
+        def xc_bca_plan_destroy(self, plan):
+            calls.append(plan)
+            return 0
+
+    monkeypatch.setattr(bc._lib, "load", lambda: FakeLib())
+    for how in ("close", "close_twice", "gc"):
+        eng = bc.BcaCsrEngine.__new__(bc.BcaCsrEngine)
+        eng._plan, eng._plan_key = object(), ("k",)
+        before = len(calls)
+        if how == "gc":
+            del eng
+        else:
+            eng.close()
+            if how == "close_twice":
+                eng.close()
+            del eng
+        assert len(calls) == before + 1, how
+    assert sum(1 for name in vars(bc.BcaCsrEngine) if name == "__del__") == 1
+
+
+def test_wave_policy_rules():
+    """WavePolicy: rows in flight per LABEL; first sweep narrower on skewed popularity; "final" parity wider;
+    the device-side form (num / changed) is the same rule."""
+    monkey_info = {"cu_count": 256, "waves_per_cu": 32}
+    orig = bc._lib.device_info
+    bc._lib.device_info = lambda: monkey_info
+    try:
+        p = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5)
+        assert p.next(None) == int(0.04 * 30_000) == 1200
+        assert p.next(50_000) == 1200 and p.next(25_000) == 2400 and p.next(10) == 8192      # cap = resident waves
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(None) == 600             # longer rows: more candidates per row
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(None) == 300             # (5 / k)^2
+        z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
+        assert z.next(None) == 150 and z.next(100_000) == 600                                   # only the FIRST sweep is narrowed
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 4800
+        num, world, min_w, max_w, fixed = p.device_params()
+        assert int(num / 50_000) == p.next(50_000) and (world, fixed, max_w) == (1, 0, 8192)
+        assert bc.WavePolicy(100_000, fixed=1, m=30_000).sequential
+        s = bc.WavePolicy(12_500, m=30_000, row_nnz=50, k=5, world=8)                           # 8 row shards
+        assert s.next(400_000) == int(0.04 * 30_000 * 12_500 / 2 / 50_000)                      # its share of the changed rows
+        with pytest.raises(ValueError):
+            bc.WavePolicy(10, parity="sometimes")
+    finally:
+        bc._lib.device_info = orig

@@ -16,11 +16,21 @@ from xcolumns_amd.synthetic import make_csr
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
-n, m, k = 40001, 3000, 5
-Y = make_csr(n, m, 30, seed=5, k=k)
+shape = os.environ.get("XC_BCA_REHEARSAL_SHAPE")   # "n,m,sweeps": the benchmark generator at that size, no sequential oracle
+if shape:
+    from xcolumns_amd.synthetic import make_csr_rows
+    n, m, sweeps = (int(x) for x in shape.split(","))
+    k = 5
+    lo, hi = shard_bounds(n, world, rank)
+    shard = make_csr_rows(n, m, lo, hi, 50, seed=20240004, k=k)
+    tol = -1.0
+else:
+    n, m, k, sweeps, tol = 40001, 3000, 5, 6, 1e-7
+    Y = make_csr(n, m, 30, seed=5, k=k)
+    shard = shard_csr(Y, world, rank)
 comm = TorchComm()
-P, meta = predict_bca_csr_sharded(shard_csr(Y, world, rank), binary_f1_score_on_conf_matrix, k, comm, skip_tn=True,
-                                  seed=13, max_iters=6, tolerance=1e-7)
+P, meta = predict_bca_csr_sharded(shard, binary_f1_score_on_conf_matrix, k, comm, skip_tn=True,
+                                  seed=13, max_iters=sweeps, tolerance=tol)
 gathered = [None] * world
 dist.all_gather_object(gathered, (meta["utilities"], meta["iters"], P.indices))
 if rank == 0:
@@ -30,11 +40,16 @@ if rank == 0:
     idx = np.concatenate([g[2] for g in gathered])
     full = csr_matrix((np.ones(n * k, dtype=np.float32), idx, np.arange(n + 1) * k), shape=(n, m))
     metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    if shape:
+        Y = make_csr_rows(n, m, 0, n, 50, seed=20240004, k=k)
     tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, full, skip_tn=True)
     u = oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n)
-    _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=6, tolerance=1e-7)
-    print("utilities", meta["utilities"], "\noracle   ", mo["utilities"], "\n|last - utility(assembled prediction)| =",
-          abs(u - meta["utilities"][-1]), "all-reduce calls", comm.calls, flush=True)
+    if shape:
+        mo = {"utilities": []}
+    else:
+        _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=6, tolerance=1e-7)
+    print("utilities", meta["utilities"], "\noracle   ", mo["utilities"], "\nexchanges", meta.get("exchanges"),
+          "\n|last - utility(assembled prediction)| =", abs(u - meta["utilities"][-1]), "all-reduce calls", comm.calls, flush=True)
     assert abs(u - meta["utilities"][-1]) < 1e-12
 dist.barrier()
 dist.destroy_process_group()

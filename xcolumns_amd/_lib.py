@@ -89,6 +89,8 @@ SIGNATURES = {
     "xc_threshold_fill_csr_rowwise": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p,
                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_pack_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xc_bca_pack_rows_from_colsum": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
     "xc_bca_accumulate_pred": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_commit_utility": (c_int, [c_int64, c_int64, c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       POINTER(XcMetric), c_int, c_void_p, c_void_p]),

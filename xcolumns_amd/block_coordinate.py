@@ -73,13 +73,13 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 # 3.3e-5 (Zipf) standard deviation in sweep 1 when only its visiting order (`seed`) changes.
 #
 # bca_parity = "per_sweep" (default): EVERY sweep within north_star's 1e-5 of the sequential reference --
-#     W_j = BETA * m * (50 / entries per row) * (5 / k)^1.5 * n / (2 * rows changed in sweep j-1)
+#     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * n / (2 * rows changed in sweep j-1)
 #     (half of the rows assumed before sweep 1), an eighth of it for the first sweep when the label
 #     popularity is skewed (hot labels present); converged sweeps use the whole GPU.
 # bca_parity = "final": four times wider -- the utility after the LAST sweep is what is held to 1e-5
 #     (intermediate sweeps of a top-k start stay within ~5e-5), for callers that only use the result.
 # A changing row moves more labels the larger k is and the trajectories then settle in different, nearly
-# equivalent optima (k = 64, n = 6000: 1.6e-4 in sweep 1 at the k = 5 width), hence (5 / k)^1.5.
+# equivalent optima (k = 64, n = 6000, m = 900: 1.6e-4 in sweep 1 at the k = 5 width, 1.3e-5 with (5 / k)^1.5), hence (5 / k)^2.
 _BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.04"))
 _SKEWED_FIRST_SWEEP = 0.125
 _FINAL_PARITY_FACTOR = 4.0
@@ -114,7 +114,7 @@ class WavePolicy:
         self.parity = default_parity() if parity is None else parity
         if self.parity not in ("per_sweep", "final"):
             raise ValueError("bca_parity must be 'per_sweep' or 'final'")
-        k_scale = min(1.0, 5.0 / max(1, int(k))) ** 1.5
+        k_scale = min(1.0, 5.0 / max(1, int(k))) ** 2
         if budget is None and _STALE_BUDGET is not None:
             budget = _STALE_BUDGET
         if budget is not None or m is None:
@@ -208,7 +208,10 @@ class BcaCsrEngine:
             use_shadow = os.environ.get("XCOLUMNS_BCA_SHADOW", "1") != "0"
         self.shadow = torch.zeros((m, 2), dtype=torch.float32, device=dev) if use_shadow else None
         self.colsum = torch.zeros(m, dtype=torch.float64, device=dev)
-        self.s_entry = torch.empty(max(1, csr.nnz), dtype=torch.float64, device=dev)
+        # float64 colsum per stored entry: read by the sweeps that do not read the packed stream (exact
+        # one-wavefront sweeps, float64 scores, XCOLUMNS_BCA_PACKED=0); allocated and filled on first need
+        self.s_entry: Optional[torch.Tensor] = None
+        self._s_entry_dirty = True
         # float32 scores: indices / data / sel / (float) s_entry interleaved in 12-byte entries, so a
         # candidate streams in as one 12-byte lane load (XCOLUMNS_BCA_PACKED=0 disables)
         self.packed = (torch.empty((max(1, csr.nnz), 3), dtype=torch.int32, device=dev)
@@ -219,12 +222,22 @@ class BcaCsrEngine:
         # A sweeping wave batches its deltas to them (xc_bca_sweep_csr `hot_labels`);
         # XCOLUMNS_BCA_HOT=0 disables.  Uniform popularity has none.
         self.hot_slot = self.hot_labels = None
-        if (self.packed is not None and self.shadow is not None and csr.nnz > 0
-                and os.environ.get("XCOLUMNS_BCA_HOT", "1") != "0"):
-            counts = torch.bincount(csr.indices, minlength=m)
+        self.skewed = False      # a label stored in >= n/32 rows: the first sweep from top-k changes nearly every row
+        if csr.nnz > 0:
+            # label frequencies from a strided sample of the stored entries (at most ~4 M of them): a label
+            # stored in n / 32 rows shows up thousands of times in it, and the hot set only steers how the
+            # kernel batches its atomics -- not worth a full histogram of the matrix (2.1 ms at 1M x 500K)
+            stride = max(1, csr.nnz // (1 << 22))
+            counts = torch.bincount(csr.indices[::stride], minlength=m) * stride
             top = torch.topk(counts, min(63, m))
-            keep = top.values >= max(512, csr.n // 32)
-            n_hot = int(keep.sum().item())
+            # "hot" presumes a record that sums so many rows that a few rows' delay cannot move a gain: at
+            # least 4096 stored entries (a label stored in 500 of 6000 rows is busy, but its tp is ~10)
+            keep = top.values >= max(4096, csr.n // 32)
+            n_hot, n_busy = (int(x) for x in torch.stack([keep.sum(), (top.values >= max(64, csr.n // 32)).sum()]).tolist())
+            self.skewed = n_busy > 0
+            if not (self.packed is not None and self.shadow is not None
+                    and os.environ.get("XCOLUMNS_BCA_HOT", "1") != "0"):
+                n_hot = 0
             if n_hot > 0:
                 labels = top.indices[:n_hot].to(torch.int32)
                 self.hot_labels = torch.full((64,), -1, dtype=torch.int32, device=dev)
@@ -274,7 +287,8 @@ class BcaCsrEngine:
     # -- plan: per-run constants bound once on the C side ------------------------------
     def _plan_handle(self):
         """(Re)bind when the prediction buffers were replaced by an init_* call."""
-        key = (self.pred_idx.data_ptr(), self.pred_eta.data_ptr())
+        key = (self.pred_idx.data_ptr(), self.pred_eta.data_ptr(),
+               0 if self.s_entry is None else self.s_entry.data_ptr())
         if getattr(self, "_plan_key", None) != key:
             self._drop_plan()
             h = ctypes.c_void_p()
@@ -310,15 +324,24 @@ class BcaCsrEngine:
             self._expand_colsum()
 
     def _expand_colsum(self):
-        c = self.csr
-        _lib.call("xc_bca_expand_colsum", c.nnz, D.ptr(c.indices), D.ptr(self.colsum), D.ptr(self.s_entry),
-                  D.stream())
+        """colsum changed: its per-entry copies (s_entry, the packed stream) are stale."""
+        self._s_entry_dirty = True
         self._pack_dirty = True
+
+    def _ensure_s_entry(self):
+        if self.s_entry is None:
+            self.s_entry = torch.empty(max(1, self.csr.nnz), dtype=torch.float64, device=self.dev)
+            self._s_entry_dirty = True
+        if self._s_entry_dirty:
+            c = self.csr
+            _lib.call("xc_bca_expand_colsum", c.nnz, D.ptr(c.indices), D.ptr(self.colsum), D.ptr(self.s_entry),
+                      D.stream())
+            self._s_entry_dirty = False
 
     def _repack(self):
         c = self.csr
-        _lib.call("xc_bca_pack_rows", c.nnz, D.ptr(c.indices), D.ptr(c.data), D.ptr(self.sel), D.ptr(self.s_entry),
-                  D.ptr(self.hot_slot), D.ptr(self.packed), D.stream())
+        _lib.call("xc_bca_pack_rows_from_colsum", c.nnz, D.ptr(c.indices), D.ptr(c.data), D.ptr(self.sel),
+                  D.ptr(self.colsum), D.ptr(self.hot_slot), D.ptr(self.packed), D.stream())
         self._pack_dirty = False
 
     def sync_column_sums(self):
@@ -370,6 +393,8 @@ class BcaCsrEngine:
         use_packed = self.packed is not None and not greedy and int(n_waves) > 1
         if use_packed and self._pack_dirty:
             self._repack()
+        if not use_packed and not greedy:
+            self._ensure_s_entry()
         _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(order), int(n_order), D.ptr(self.orphans),
                   int(bool(greedy)), int(n_waves), int(full), int(use_packed),
                   None if full else D.ptr(self.changed), D.stream())
@@ -412,6 +437,8 @@ class BcaCsrEngine:
         if self.packed is not None and self._pack_dirty:
             self._repack()
         use_packed = self.packed is not None
+        if not use_packed:
+            self._ensure_s_entry()
         n = self.csr.n
         segments = 1
         if self.comm is not None and self.shadow is not None:
@@ -502,27 +529,108 @@ class BcaCsrEngine:
         return out
 
 
-class _OrderSource:
-    """Visiting order per sweep (block_coordinate.py:413-419)."""
+_ORDER_PREFETCH_ROWS = 50_000   # below this a sweep's order is cheaper to make in line than to hand over
+_ORDER_PREFETCH_DEPTH = 3        # orders generated ahead of the sweep that consumes them
 
-    def __init__(self, n: int, seed, shuffle: bool, backend: str, dev):
+
+class _OrderSource:
+    """Visiting order per sweep (block_coordinate.py:413-419): the reference's stream --
+    ``np.random.default_rng(seed)``, ONE array shuffled cumulatively, once per iteration.
+
+    The shuffle is sequential host work (7.6 ms for 1 M rows, 12x the sweep it feeds), so for large
+    matrices it runs on a worker thread, up to _ORDER_PREFETCH_DEPTH sweeps ahead (numpy releases the GIL
+    inside ``Generator.shuffle``): the order of sweep j + 1 is shuffled, narrowed to int32 into a pinned
+    buffer and copied to the GPU on a side stream while sweep j runs; ``next()`` makes the compute stream
+    wait for that copy only.  Same stream, same orders -- the loop just stops waiting for them."""
+
+    def __init__(self, n: int, seed, shuffle: bool, backend: str, dev, prefetch: Optional[bool] = None):
         self.n, self.shuffle, self.backend, self.dev = n, shuffle, backend, dev
         if backend not in ("numpy", "device"):
             raise ValueError("order_backend must be 'numpy' or 'device'")
         self.rng = np.random.default_rng(seed)       # :413
         self.order = np.arange(n)                     # :414, shuffled cumulatively
         self.gen = None
+        self._thread = None
         if backend == "device" and shuffle:
             self.gen = torch.Generator(device=dev)
             self.gen.manual_seed(int(seed) if seed is not None else int(self.rng.integers(2 ** 31)))
+        if prefetch is None:
+            prefetch = os.environ.get("XCOLUMNS_ORDER_PREFETCH", "1") != "0"
+        if backend == "numpy" and shuffle and prefetch and n >= _ORDER_PREFETCH_ROWS:
+            import queue
+            import threading
+            self._q = queue.Queue(maxsize=_ORDER_PREFETCH_DEPTH - 1)
+            self._stop = threading.Event()
+            self._error = None
+            self._thread = threading.Thread(target=self._produce, name="xcolumns-order", daemon=True)
+            self._thread.start()
+
+    def _produce(self):
+        try:
+            torch.cuda.set_device(self.dev)
+            side = torch.cuda.Stream(device=self.dev)
+            slots = _ORDER_PREFETCH_DEPTH + 1      # one being filled, DEPTH - 1 queued, one in the consumer's hands
+            pinned = [torch.empty(self.n, dtype=torch.int32).pin_memory() for _ in range(slots)]
+            done = [None] * slots
+            i = 0
+            while not self._stop.is_set():
+                slot = i % slots
+                if done[slot] is not None:
+                    done[slot].synchronize()          # its previous copy has left the pinned buffer
+                self.rng.shuffle(self.order)          # :418-419 (GIL released)
+                np.copyto(pinned[slot].numpy(), self.order, casting="unsafe")
+                with torch.cuda.stream(side):
+                    d = pinned[slot].to(self.dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                done[slot] = ev
+                i += 1
+                while not self._stop.is_set():
+                    try:
+                        self._q.put((d, ev), timeout=0.05)
+                        break
+                    except Exception:
+                        continue
+        except BaseException as e:                    # surfaced by next()
+            self._error = e
+            try:
+                self._q.put_nowait(None)
+            except Exception:
+                pass
 
     def next(self) -> Optional[torch.Tensor]:
         if not self.shuffle:
             return None
+        if self._thread is not None:
+            item = self._q.get()
+            if item is None or self._error is not None:
+                raise RuntimeError(f"visiting-order worker failed: {self._error!r}")
+            d, ev = item
+            torch.cuda.current_stream().wait_event(ev)
+            d.record_stream(torch.cuda.current_stream())
+            return d
         if self.backend == "numpy":
             self.rng.shuffle(self.order)              # :418-419
             return torch.from_numpy(self.order.astype(np.int32)).to(self.dev, non_blocking=True)
         return torch.randperm(self.n, generator=self.gen, device=self.dev, dtype=torch.int32)
+
+    def close(self):
+        """Stop the worker (orders generated ahead of an early stop are dropped)."""
+        if self._thread is not None:
+            self._stop.set()
+            try:
+                while True:
+                    self._q.get_nowait()
+            except Exception:
+                pass
+            self._thread.join(timeout=5.0)
+            self._thread = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------------
@@ -709,11 +817,18 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
         bca_waves = 1
     # a random / foreign / greedy start changes every row in sweep 1 and keeps many rows moving for several
     # sweeps (measured 5e-5 .. 1.2e-4 at the top-k width): half the budget for the whole run
-    policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if init_idx is None else 1.0,
-                        m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.hot_labels is not None,
-                        parity=bca_parity, scale=1.0 if init_idx is None else 0.5)
-    run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
-                   policy, verbose, meta)
+    # a random / foreign / greedy start -- and a minimisation from the top-k start, the worst point for it --
+    # changes every row in sweep 1 and keeps many rows moving for several sweeps (measured 1.0-1.1e-5 in sweep 1
+    # at half the top-k width): a quarter of the width for the whole run
+    calm = init_idx is None and maximize
+    policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if calm else 1.0,
+                        m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.skewed,
+                        parity=bca_parity, scale=1.0 if calm else 0.25)
+    try:
+        run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
+                       policy, verbose, meta)
+    finally:
+        orders.close()
 
     pred_idx = eng.pred_idx
     eng.close()
@@ -797,7 +912,7 @@ def _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maxi
     stats = torch.zeros((4, m), dtype=torch.float64, device=dev)
     work = torch.empty(m, dtype=torch.float64, device=dev)
     partials = torch.zeros(_lib.XC_UTILITY_PARTIALS + 1, dtype=torch.float64, device=dev)
-    orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
+    orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev, prefetch=False)
     # rows in flight: the CSR policy (one workgroup here = one "wavefront" there), bounded by the
     # workgroups the GPU holds; bca_waves=1 is the reference's sequential sweep
     if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
@@ -1028,7 +1143,7 @@ def predict_optimizing_coverage_using_bc(
             cov = alpha * cov + (1 - alpha) * float(pred_eta.to(torch.float64).sum().item()) / n / k
         return cov
 
-    orders = _OrderSource(n, seed, shuffle_order, order_backend, dev)
+    orders = _OrderSource(n, seed, shuffle_order, order_backend, dev, prefetch=False)
     # The multiplicative statistic reacts far more strongly to a row in flight than the additive ones,
     # and the coverage landscape has many nearly equivalent optima: runs with a few rows in flight end
     # 1-3e-5 from the sequential run even after 8 sweeps (20K x 30K Zipf; 1.6e-4 .. 2.8e-4 per sweep at the

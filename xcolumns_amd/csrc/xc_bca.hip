@@ -755,6 +755,24 @@ __global__ __launch_bounds__(XC_BLOCK) void pack_rows_kernel(int64_t nnz, const 
     }
 }
 
+// the same straight from the per-label column sums (one L2-resident gather per entry): the float64
+// per-entry expansion is then needed only by the sweeps that do not read the packed stream
+__global__ __launch_bounds__(XC_BLOCK) void pack_rows_colsum_kernel(int64_t nnz, const int32_t *indices,
+                                                                    const float *data, const uint8_t *sel,
+                                                                    const double *colsum, const uint8_t *hot_slot,
+                                                                    pack3_t *packed) {
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < nnz; t += stride) {
+        pack3_t w;
+        const unsigned col = (unsigned)__builtin_nontemporal_load(indices + t);
+        w.x = col | ((hot_slot ? (unsigned)hot_slot[col] & XC_PACK_HOT_MASK : 0u) << XC_PACK_HOT_SHIFT) |
+              (__builtin_nontemporal_load(sel + t) ? 0x80000000u : 0u);
+        w.y = __float_as_uint(__builtin_nontemporal_load(data + t));
+        w.z = __float_as_uint((float)colsum[col]);
+        packed[t] = w;
+    }
+}
+
 // ---- tp / fp of the current prediction from scratch ------------------------------
 template <typename T>
 __global__ __launch_bounds__(XC_BLOCK) void accumulate_pred_kernel(int64_t n_k, const int32_t *pred_indices,
@@ -1069,6 +1087,17 @@ int xc_bca_pack_rows(int64_t nnz, const int32_t *indices, const float *data, con
     return XC_OK;
 }
 
+int xc_bca_pack_rows_from_colsum(int64_t nnz, const int32_t *indices, const float *data, const uint8_t *sel,
+                                 const double *colsum, const uint8_t *hot_slot, void *packed, void *stream) {
+    if (nnz < 0 || (nnz > 0 && (!indices || !data || !sel || !colsum || !packed)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_pack_rows_from_colsum: bad argument");
+    if (nnz == 0) return XC_OK;
+    hipLaunchKernelGGL(xc::pack_rows_colsum_kernel, dim3(xc::grid_for(nnz)), dim3(XC_BLOCK), 0, xc::as_stream(stream), nnz,
+                       indices, data, sel, colsum, hot_slot, static_cast<xc::pack3_t *>(packed));
+    XC_CHECK_LAUNCH("pack_rows_colsum_kernel");
+    return XC_OK;
+}
+
 int xc_bca_accumulate_pred(int64_t n_k, const int32_t *pred_indices, const void *pred_eta, int dtype,
                            double *acc, void *stream) {
     if (n_k < 0 || (n_k > 0 && (!pred_indices || !pred_eta || !acc)))
@@ -1146,8 +1175,8 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
         !metric_host)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
-    if (!greedy && !s_entry)
-        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: s_entry is required unless greedy");
+    if (!greedy && !s_entry && !(packed && n_waves > 1))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: s_entry is required unless greedy or a concurrent sweep over the packed stream");
     if (m > (int64_t)(0xFFFFFFFFu / 16))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: m too large for 32-bit record offsets");
     if (packed && m > (int64_t)XC_PACK_COL_MASK + 1)

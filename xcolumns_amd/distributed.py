@@ -236,7 +236,7 @@ def predict_bca_csr_sharded(
 
     meta = {"utilities": [], "iters": 0, "time": time()}
     policy = (bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world, k=k, m=m,
-                            row_nnz=y_proba_shard.nnz / max(1, n_local), skewed=eng.hot_labels is not None)
+                            row_nnz=y_proba_shard.nnz / max(1, n_local), skewed=eng.skewed)
               if engine_factory is None else _FixedWaves(bca_waves or 1))
     bc.run_bca_sweeps(eng, next_order, n_local, n_total, m, metric_aggregation, maximize, tolerance, max_iters,
                       False, policy, verbose, meta)
