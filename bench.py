@@ -385,14 +385,18 @@ def worker(args):
             comm.bytes_reduced = comm.calls = 0
         t = Timer(eng, policy, orders, n_local, n_global, m, comm, world, dev)
         res = t.measure(args.warmup, args.steps, repeats)
+        used = [int(x) for x in getattr(eng, "exchanges_used", [])[-args.steps:]] or [1] * args.steps
         res.update(n_local=n_local, n_global=n_global, Y=Y, eng=eng,
                    pipelined=eng.can_pipeline(n_local) and not policy.sequential,
-                   exchanges=eng.exchanges, hot=eng.hot_labels is not None)
+                   exchanges=used, hot=eng.hot_labels is not None)
         if comm is not None:
             per_sweep = max(1, (args.warmup + args.steps * repeats))
+            extra = (sum(used) / len(used) - 1.0) if eng.shadow is not None else 0.0
             res["comm"] = {"backend": backend, "world_size": dist.get_world_size(),
-                           "all_reduce_bytes_per_sweep": (2 * m + 1) * 8 + (eng.exchanges - 1) * 2 * m * 4
-                           if eng.shadow is not None else (2 * m + 1) * 8,
+                           "exchanges_per_sweep": used,
+                           "all_reduce_bytes_per_sweep": (2 * m + 1) * 8 + extra * 2 * m * 4,
+                           "all_reduce_bytes_note": "boundary: 2m+1 float64 (from-scratch tp/fp + changed-row count); each "
+                                                    "mid-sweep exchange: 2m float32 (what the rank's rows changed in the records)",
                            "all_reduce_calls_total": comm.calls, "all_reduce_bytes_total": comm.bytes_reduced,
                            "all_reduce_ms_per_sweep": (_median([x / args.steps for x in res["allreduce_ms"]])
                                                        if res["allreduce_ms"] else None),

@@ -317,6 +317,14 @@ int xc_bca_time_next_sweep(void *start, void *stop);
  *   0            none. */
 int xc_bca_set_validation(int mode);
 
+/* Two constants of the concurrent sweep (process-wide, studies; negative = leave as is):
+ *   conflict_rel     commit protocol: a returned record that differs from the scored one by less than this
+ *                    share of (tp + fp) does not count as a conflict (default 1/512: one other row changing a
+ *                    label that holds fewer than 512 predicted rows re-processes this row);
+ *   hot_unpublished  hot labels: share of the rows whose deltas may wait in the workgroups' LDS tables
+ *                    (default 0.05; sets how often a narrow sweep publishes them). */
+int xc_bca_set_tuning(double conflict_rel, double hot_unpublished);
+
 /* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */
 int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum,

@@ -109,6 +109,7 @@ SIGNATURES = {
     "xc_bca_plan_boundary": (c_int, [c_void_p, c_int64, c_double, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                      c_void_p]),
     "xc_bca_set_validation": (c_int, [c_int]),
+    "xc_bca_set_tuning": (c_int, [c_double, c_double]),
     "xc_event_create": (c_int, [POINTER(c_void_p)]),
     "xc_event_destroy": (c_int, [c_void_p]),
     "xc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_float)]),

@@ -99,7 +99,8 @@ class WavePolicy:
 
     def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None,
                  world: int = 1, k: int = 5, first_changed: float = 0.5, m: Optional[int] = None,
-                 row_nnz: float = 50.0, skewed: bool = False, parity: Optional[str] = None, scale: float = 1.0):
+                 row_nnz: float = 50.0, skewed: bool = False, parity: Optional[str] = None, scale: float = 1.0,
+                 first_sequential: bool = False):
         """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows (the changed-row
         count fed to :meth:`next` is the global one); `k`: labels per row; `first_changed`: expected share
         of rows the first sweep changes (about half from the top-k prediction, all of them from a random
@@ -107,6 +108,9 @@ class WavePolicy:
         (first sweep narrower); `parity`: "per_sweep" | "final"; `scale`: extra factor on the width.
         `budget` (or XCOLUMNS_BCA_STALE_BUDGET) selects the round-1 rule instead: W = budget * n^2 / changed."""
         self.first_changed = float(first_changed)
+        # the first sweep of a random / foreign start changes every label of every row: it runs as the
+        # reference's sequential sweep (exact) unless the caller asked for "final" parity or a fixed width
+        self.first_sequential = bool(first_sequential)
         self.world = max(1, int(world))
         env = os.environ.get("XCOLUMNS_BCA_WAVES")
         self.fixed = int(fixed) if fixed else (int(env) if env else None)
@@ -122,7 +126,12 @@ class WavePolicy:
             self.num = b * k_scale * float(self.n) * float(self.n)
             self.first_factor = 1.0
         else:
-            width = _BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
+            # labels that hold about one predicted row each (n * k / m ~ 1: 150 K rows x 670 K labels) react to a
+            # single row in flight with their whole statistic, and the differences no longer heal -- the
+            # landscape is full of nearly equivalent optima (C3: 1e-5 at 0.4 % of the rows in flight, in every
+            # sweep): the width shrinks with the square of the predicted rows per label below 16
+            per_label = float(self.n) * self.world * max(1, int(k)) / float(m)
+            width = _BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale) * min(1.0, per_label / 16.0) ** 2
             if self.parity == "final":
                 width *= _FINAL_PARITY_FACTOR
             self.num = width * self.n / 2.0
@@ -142,6 +151,8 @@ class WavePolicy:
         # sharded rows: the other ranks' updates are invisible within a sweep whatever W is (DESIGN.md
         # section 7), but this rank's own rows still follow the rule, on its share of the changes
         if changed_prev is None:
+            if self.first_sequential:
+                return 1
             want = int(self.num * self.first_factor / (self.n * self.first_changed))
         else:
             want = int(self.num / max(1.0, changed_prev / self.world))
@@ -652,7 +663,7 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
     div = m if metric_aggregation == "mean" else 1
     for j in range(1, max_iters + 1):
         if (not greedy and not getattr(policy, "sequential", True) and hasattr(eng, "can_pipeline")
-                and eng.can_pipeline(n_order)):
+                and eng.can_pipeline(n_order) and not (j == 1 and getattr(policy, "first_sequential", False))):
             # every remaining sweep is a full concurrent one: hand the stopping rule to the GPU
             if new_utility_sum is None:
                 if j == 1:
@@ -820,10 +831,13 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
     # a random / foreign / greedy start -- and a minimisation from the top-k start, the worst point for it --
     # changes every row in sweep 1 and keeps many rows moving for several sweeps (measured 1.0-1.1e-5 in sweep 1
     # at half the top-k width): a quarter of the width for the whole run
+    normalize_first = n_u >= n_rows
     calm = init_idx is None and maximize
+    parity = default_parity() if bca_parity is None else bca_parity
     policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if calm else 1.0,
                         m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.skewed,
-                        parity=bca_parity, scale=1.0 if calm else 0.25)
+                        parity=parity, scale=1.0 if calm else 0.25,
+                        first_sequential=init_idx is not None and not greedy and parity == "per_sweep" and normalize_first)
     try:
         run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                        policy, verbose, meta)

@@ -78,6 +78,10 @@ struct SweepParams {
     int n_waves;
     int validate; // concurrent mode: 0 = none, 1 = re-read the records of the labels a row is about to
                   // change, 2 = commit them with returning atomics and compare (the default)
+    float hot_unpublished; // HOT: share of the rows whose hot-label deltas may wait in the workgroups' LDS tables
+    float conflict_rel;   // commit protocol: a returned record that differs from the scored one by less than
+                          // this share of (tp + fp) is not a conflict (a label that sums hundreds of rows moves
+                          // all the time and one row's change cannot move its gain)
     unsigned long long *changed;
     unsigned long long *stamps; // diagnostic builds only (-DXC_STAMPS): per-phase cycle sums
     const double *ctrl;         // optional device-side loop control (XC_CTRL_*): stop flag and wave count
@@ -253,6 +257,12 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                                      ? (n_walk - (int64_t)blockIdx.x * (XC_BLOCK / XC_WAVE))
                                      : (XC_BLOCK / XC_WAVE));
     int hot_rows = 0;
+    // A wave ticks the workgroup's publication counter every hot_flush_rows rows, so about hot_flush_rows / 2
+    // rows per wavefront are unpublished at any time: keep that below P.hot_unpublished of the rows whatever
+    // the width -- a narrow sweep publishes less often (publications serialise at the memory side, ~80 ns
+    // each per record: n / (4 * hot_flush_rows) of them per hot record and sweep).
+    int hot_flush_rows = (int)(2.0f * P.hot_unpublished * (float)P.n_order / (float)n_walk);
+    hot_flush_rows = hot_flush_rows < XC_HOT_FLUSH_ROWS ? XC_HOT_FLUSH_ROWS : (hot_flush_rows > 64 ? 64 : hot_flush_rows);
     auto flush_hot = [&]() { // whoever exchanges a non-zero sum out of the table publishes it
         if (my_hot_label >= 0) {
             const float a = __hip_atomic_exchange(&s_hot[lane][0], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -508,7 +518,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                         float *sh = P.shadow + (int64_t)cur.idx[c] * 2;
                         const float was_tp = atomic_add_ret_f32(sh + 0, (float)(sgn * ed));
                         const float was_fp = atomic_add_ret_f32(sh + 1, (float)(sgn * omd));
-                        conflict = conflict || was_tp != rec32[c].x || was_fp != rec32[c].y;
+                        conflict = conflict || (fabsf(was_tp - rec32[c].x) + fabsf(was_fp - rec32[c].y) >
+                                                P.conflict_rel * (rec32[c].x + rec32[c].y));
                         if (!P.acc) { // the float64 records are read again before a commit kernel rewrites them
                             atomic_add_f64(P.tpfp + (int64_t)cur.idx[c] * 2, sgn * ed);
                             atomic_add_f64(P.tpfp + (int64_t)cur.idx[c] * 2 + 1, sgn * omd);
@@ -517,7 +528,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                         double *st = P.tpfp + (int64_t)cur.idx[c] * 2;
                         const double was_tp = atomic_add_ret_f64(st + 0, sgn * ed);
                         const double was_fp = atomic_add_ret_f64(st + 1, sgn * omd);
-                        conflict = conflict || was_tp != rec64[c].x || was_fp != rec64[c].y;
+                        conflict = conflict || (fabs(was_tp - rec64[c].x) + fabs(was_fp - rec64[c].y) >
+                                                (double)P.conflict_rel * (rec64[c].x + rec64[c].y));
                         if (P.shadow) { // keep the float32 copy in step
                             atomic_add_f32(P.shadow + (int64_t)cur.idx[c] * 2, (float)(sgn * ed));
                             atomic_add_f32(P.shadow + (int64_t)cur.idx[c] * 2 + 1, (float)(sgn * omd));
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             }
             if (row_changed) ++n_changed;
         }
-        if (hot_on && ++hot_rows >= XC_HOT_FLUSH_ROWS) { // one publication per round of the workgroup's waves
+        if (hot_on && ++hot_rows >= hot_flush_rows) { // one publication per round of the workgroup's waves
             hot_rows = 0;
             int tick = 0;
             if (lane == 0) tick = __hip_atomic_fetch_add(&s_hot_ticks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -958,6 +970,8 @@ static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stam
 // one-shot HIP events recorded tightly around the NEXT sweep launch (xc_bca_time_next_sweep)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_validate = 2;                           // xc_bca_set_validation: 2 = commit protocol
+static float g_conflict_rel = 1.0f / 512.0f;         // xc_bca_set_tuning
+static float g_hot_unpublished = 0.05f;              // xc_bca_set_tuning: share of the rows whose hot-label deltas may be unpublished
 
 template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
 static void launch_sweep_one(const SweepParams<T> &P, hipStream_t st) {
@@ -1200,14 +1214,14 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
                                  static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
                                  static_cast<xc::pack3_t *>(packed), packed ? hot_labels : nullptr, acc, m,
                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
-                                 (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
+                                 (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate, xc::g_hot_unpublished, xc::g_conflict_rel,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
                                   static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
                                   nullptr, nullptr, acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
-                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate,
+                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate, xc::g_hot_unpublished, xc::g_conflict_rel,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
     }
@@ -1250,6 +1264,12 @@ int xc_event_elapsed_ms(void *start, void *stop, float *ms_host) {
 int xc_bca_time_next_sweep(void *start, void *stop) {
     xc::g_ev_start = static_cast<hipEvent_t>(start);
     xc::g_ev_stop = static_cast<hipEvent_t>(stop);
+    return XC_OK;
+}
+
+int xc_bca_set_tuning(double conflict_rel, double hot_unpublished) {
+    if (conflict_rel >= 0.0) xc::g_conflict_rel = (float)conflict_rel;
+    if (hot_unpublished >= 0.0) xc::g_hot_unpublished = (float)hot_unpublished;
     return XC_OK;
 }
 
