@@ -275,7 +275,7 @@ def test_wave_policy_rules():
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(None) == 600             # longer rows: more candidates per row
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(None) == 300             # (5 / k)^2
         z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
-        assert z.next(None) == 150 and z.next(100_000) == 600                                   # only the FIRST sweep is narrowed
+        assert z.next(None) == 60 and z.next(100_000) == 600                                   # only the FIRST sweep is narrowed
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 4800
         num, world, min_w, max_w, fixed = p.device_params()
         assert int(num / 50_000) == p.next(50_000) and (world, fixed, max_w) == (1, 0, 8192)

@@ -31,7 +31,7 @@ def short(name):
     return name.split("(")[0][:70]
 
 
-print(f"# rocprofv3 summary, tag={tag} (python3 bench.py --no-cpu-baseline; MI355X gfx950)")
+print(f"# rocprofv3 summary, tag={tag} (python3 bench.py --no-cpu-baseline --no-extras --repeats 1 [args]; MI355X gfx950)")
 f = one(f"prof_{tag}_trace/**/*_kernel_stats.csv")
 if f:
     print("\n## kernel stats (--kernel-trace --stats), all launches incl. setup and warm-up")
