@@ -173,11 +173,19 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
     // hot-label delta table of the workgroup (see flush_hot below): zeroed before any wave leaves
     __shared__ float s_hot[XC_WAVE][2];
+    // ... and the workgroup's copy of the hot RECORDS: the published value as of its last flush.  Rows read
+    // their hot candidates from here (published + this workgroup's pending deltas) instead of gathering the
+    // 63 lines every publication of every workgroup rewrites -- 17 M gathers of lines that the atomics keep
+    // dropping from the L2s were the largest single cost of a first sweep on Zipf popularity.
+    __shared__ float s_hotrec[XC_WAVE][2];
     __shared__ int s_hot_ticks, s_hot_done;
     if (HOT) {
         if (threadIdx.x < XC_WAVE) {
             s_hot[threadIdx.x][0] = 0.0f;
             s_hot[threadIdx.x][1] = 0.0f;
+            const int hl = P.hot_labels[threadIdx.x];
+            s_hotrec[threadIdx.x][0] = hl >= 0 ? __hip_atomic_load(P.shadow + (int64_t)hl * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            s_hotrec[threadIdx.x][1] = hl >= 0 ? __hip_atomic_load(P.shadow + (int64_t)hl * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
         }
         if (threadIdx.x == 0) s_hot_ticks = s_hot_done = 0;
         __syncthreads();
@@ -263,15 +271,35 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     // each per record: n / (4 * hot_flush_rows) of them per hot record and sweep).
     int hot_flush_rows = (int)(2.0f * P.hot_unpublished * (float)P.n_order / (float)n_walk);
     hot_flush_rows = hot_flush_rows < XC_HOT_FLUSH_ROWS ? XC_HOT_FLUSH_ROWS : (hot_flush_rows > 64 ? 64 : hot_flush_rows);
-    auto flush_hot = [&]() { // whoever exchanges a non-zero sum out of the table publishes it
+    auto flush_hot = [&]() { // lane h publishes the workgroup's sum for hot slot h and refreshes its copy of the record
         if (my_hot_label >= 0) {
             const float a = __hip_atomic_exchange(&s_hot[lane][0], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const float b = __hip_atomic_exchange(&s_hot[lane][1], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // until the atomics return, readers keep seeing this workgroup's own part (copy + a)
+            s_hotrec[lane][0] += a;
+            s_hotrec[lane][1] += b;
 #ifndef XC_EXP_SKIP_HOT
-            if (a != 0.0f) atomic_add_f32(P.shadow + (int64_t)my_hot_label * 2, a);
-            if (b != 0.0f) atomic_add_f32(P.shadow + (int64_t)my_hot_label * 2 + 1, b);
+            float *rec = P.shadow + (int64_t)my_hot_label * 2;
+            // the returning add hands back what every OTHER workgroup has published meanwhile
+            const float na = a != 0.0f ? atomic_add_ret_f32(rec, a) + a
+                                       : __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float nb = b != 0.0f ? atomic_add_ret_f32(rec + 1, b) + b
+                                       : __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_hotrec[lane][0] = na;
+            s_hotrec[lane][1] = nb;
 #endif
         }
+    };
+    // a candidate's float32 record: hot labels from the workgroup's LDS copy (no request leaves the lane: an
+    // offset past the buffer's end returns zeros without touching memory), the others gathered coherently
+    auto gather32 = [&](int col, int hot) -> float2_t {
+        const unsigned off = (hot_on && hot != 0) ? 0xFFFFFFF0u : (unsigned)col * 8u;
+        float2_t v = __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, (int)off, 0, XC_CPOL_SC1));
+        if (hot_on && hot != 0) {
+            v.x = s_hotrec[hot][0] + s_hot[hot][0];
+            v.y = s_hotrec[hot][1] + s_hot[hot][1];
+        }
+        return v;
     };
     XC_STAMP_DECL;
     XC_STAMP_START();
@@ -290,8 +318,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (SHADOW) {
-                rec32[c] = __builtin_bit_cast(
-                    float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
+                rec32[c] = gather32(cur.idx[c], cur.hot[c]);
             } else {
                 rec64[c] = __builtin_bit_cast(
                     double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
@@ -567,8 +594,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (SHADOW)
-                rec32[c] = __builtin_bit_cast(
-                    float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, cur.idx[c] * 8, 0, XC_CPOL_SC1));
+                rec32[c] = gather32(cur.idx[c], cur.hot[c]);
             else
                 rec64[c] = __builtin_bit_cast(
                     double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
