@@ -325,6 +325,14 @@ int xc_bca_set_validation(int mode);
  *                    (default 0.05; sets how often a narrow sweep publishes them). */
 int xc_bca_set_tuning(double conflict_rel, double hot_unpublished);
 
+/* Host-side: one `Generator.shuffle(order)` of numpy's PCG64 stream -- the reference's visiting order of a sweep
+ * (block_coordinate.py:413-419) -- in place on an int32 array of n entries (host memory).  state_io =
+ * {state_hi, state_lo, inc_hi, inc_lo} of rng.bit_generator.state["state"], has_uint32_io / uinteger_io the
+ * generator's buffered 32-bit half; all are left as numpy would leave them.  Same permutation as numpy, less time
+ * (draws generated a block ahead, the swap partner prefetched). */
+int xc_host_shuffle_pcg64(uint64_t *state_io, int *has_uint32_io, uint32_t *uinteger_io, int64_t n,
+                          int32_t *order);
+
 /* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */
 int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum,

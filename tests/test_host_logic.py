@@ -275,7 +275,7 @@ def test_wave_policy_rules():
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(None) == 600             # longer rows: more candidates per row
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(None) == 300             # (5 / k)^2
         z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
-        assert z.next(None) == 60 and z.next(100_000) == 600                                   # only the FIRST sweep is narrowed
+        assert z.next(None) == int(1200 * 0.125 * 30_000 / 200_000) == 22 and z.next(100_000) == 600                                   # only the FIRST sweep is narrowed
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 4800
         num, world, min_w, max_w, fixed = p.device_params()
         assert int(num / 50_000) == p.next(50_000) and (world, fixed, max_w) == (1, 0, 8192)
@@ -286,3 +286,30 @@ def test_wave_policy_rules():
             bc.WavePolicy(10, parity="sometimes")
     finally:
         bc._lib.device_info = orig
+
+
+def test_host_shuffle_is_numpys_stream():
+    """xc_host_shuffle_pcg64 (csrc/xc_order.hip, host code): the same permutation as np.random.Generator.shuffle
+    -- the reference's visiting order, block_coordinate.py:413-419 -- for cumulative shuffles, array lengths on
+    both sides of the powers of two where the rejection mask changes, and with the generator's buffered 32-bit
+    half in either state; the numpy Generator is left in numpy's own state (mixed use stays in step)."""
+    from xcolumns_amd.utils import Pcg64Shuffler
+
+    assert Pcg64Shuffler.usable()
+    for seed, n in ((0, 1), (1, 2), (2, 3), (3, 255), (4, 256), (5, 257), (6, 511), (7, 513), (8, 4097), (9, 65537), (13, 200_003)):
+        a, b = np.random.default_rng(seed), np.random.default_rng(seed)
+        if seed % 2:                       # leave a buffered 32-bit half behind
+            assert a.integers(0, 100, dtype=np.uint32) == b.integers(0, 100, dtype=np.uint32)
+        ref = np.arange(n)
+        mine = Pcg64Shuffler(b, n)
+        for sweep in range(4):
+            a.shuffle(ref)
+            got = mine.shuffle()
+            assert got.dtype == np.int32 and np.array_equal(got, ref), (seed, n, sweep)
+            if sweep == 1:                 # numpy's own shuffle in between, on both sides
+                a.shuffle(ref)
+                tmp = mine.order.astype(np.int64)
+                b.shuffle(tmp)
+                mine.order[:] = tmp
+                assert np.array_equal(mine.order, ref)
+        assert a.random(3).tolist() == b.random(3).tolist()

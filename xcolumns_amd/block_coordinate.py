@@ -74,14 +74,14 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 #
 # bca_parity = "per_sweep" (default): EVERY sweep within north_star's 1e-5 of the sequential reference --
 #     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * n / (2 * rows changed in sweep j-1)
-#     (half of the rows assumed before sweep 1), a twentieth of it for the first sweep when the label
+#     (half of the rows assumed before sweep 1), an eighth of it (less when m < 200 K) for the first sweep when the label
 #     popularity is skewed (hot labels present); converged sweeps use the whole GPU.
 # bca_parity = "final": four times wider -- the utility after the LAST sweep is what is held to 1e-5
 #     (intermediate sweeps of a top-k start stay within ~5e-5), for callers that only use the result.
 # A changing row moves more labels the larger k is and the trajectories then settle in different, nearly
 # equivalent optima (k = 64, n = 6000, m = 900: 1.6e-4 in sweep 1 at the k = 5 width, 1.3e-5 with (5 / k)^1.5), hence (5 / k)^2.
 _BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.04"))
-_SKEWED_FIRST_SWEEP = 0.05
+_SKEWED_FIRST_SWEEP = 0.125
 _FINAL_PARITY_FACTOR = 4.0
 _STALE_BUDGET = float(os.environ["XCOLUMNS_BCA_STALE_BUDGET"]) if "XCOLUMNS_BCA_STALE_BUDGET" in os.environ else None
 _MIN_WAVES = 1
@@ -131,11 +131,19 @@ class WavePolicy:
             # landscape is full of nearly equivalent optima (C3: 1e-5 at 0.4 % of the rows in flight, in every
             # sweep): the width shrinks with the square of the predicted rows per label below 16
             per_label = float(self.n) * self.world * max(1, int(k)) / float(m)
-            width = _BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale) * min(1.0, per_label / 16.0) ** 2
+            # and the bar is absolute: one label's F1 weighs 1 / m in the utility, so on a small label space a
+            # handful of decisions that fall the other way are already 1e-5 (20 K x 5 K: 1.0-1.7e-5 at 0.064 m
+            # rows in flight, 4e-6 at half of that)
+            small_m = min(1.0, float(m) / 30000.0) ** 0.5
+            width = (_BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
+                     * min(1.0, per_label / 16.0) ** 2 * small_m)
             if self.parity == "final":
                 width *= _FINAL_PARITY_FACTOR
             self.num = width * self.n / 2.0
-            self.first_factor = _SKEWED_FIRST_SWEEP if skewed else 1.0
+            # skewed popularity: every row changes in sweep 1, mostly into tail labels that hold one or two rows --
+            # a single decision that falls the other way moves such a label's F1 by ~0.3, i.e. the utility by
+            # 0.3 / m: on a 30 K-label space three of them are the whole 1e-5
+            self.first_factor = _SKEWED_FIRST_SWEEP * min(1.0, float(m) / 200000.0) if skewed else 1.0
         self.budget = self.num / (float(self.n) * float(self.n))   # the same rule as a share of n (diagnostics)
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
@@ -562,6 +570,14 @@ class _OrderSource:
         self.order = np.arange(n)                     # :414, shuffled cumulatively
         self.gen = None
         self._thread = None
+        # the same walk and stream as rng.shuffle, 2-3x faster (utils.Pcg64Shuffler); numpy's own when it is not
+        # the PCG64 generator this build was checked against, or for small orders
+        self._fast = None
+        if (backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS
+                and os.environ.get("XCOLUMNS_ORDER_FAST_SHUFFLE", "1") != "0"):
+            from .utils import Pcg64Shuffler
+            if Pcg64Shuffler.usable():
+                self._fast = Pcg64Shuffler(self.rng, n)
         if backend == "device" and shuffle:
             self.gen = torch.Generator(device=dev)
             self.gen.manual_seed(int(seed) if seed is not None else int(self.rng.integers(2 ** 31)))
@@ -588,8 +604,11 @@ class _OrderSource:
                 slot = i % slots
                 if done[slot] is not None:
                     done[slot].synchronize()          # its previous copy has left the pinned buffer
-                self.rng.shuffle(self.order)          # :418-419 (GIL released)
-                np.copyto(pinned[slot].numpy(), self.order, casting="unsafe")
+                if self._fast is not None:
+                    np.copyto(pinned[slot].numpy(), self._fast.shuffle())   # :418-419, int32 walk (GIL released in ctypes)
+                else:
+                    self.rng.shuffle(self.order)      # :418-419 (GIL released)
+                    np.copyto(pinned[slot].numpy(), self.order, casting="unsafe")
                 with torch.cuda.stream(side):
                     d = pinned[slot].to(self.dev, non_blocking=True)
                     ev = torch.cuda.Event()
@@ -621,6 +640,8 @@ class _OrderSource:
             d.record_stream(torch.cuda.current_stream())
             return d
         if self.backend == "numpy":
+            if self._fast is not None:
+                return torch.from_numpy(self._fast.shuffle().copy()).to(self.dev, non_blocking=True)
             self.rng.shuffle(self.order)              # :418-419
             return torch.from_numpy(self.order.astype(np.int32)).to(self.dev, non_blocking=True)
         return torch.randperm(self.n, generator=self.gen, device=self.dev, dtype=torch.int32)

@@ -287,47 +287,19 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         const int rounds = (int)wave_umax32((unsigned)want);
 #endif
         const unsigned my_bit = 1u << l16;
-        // Fast rounds: every lane whose head equals the row maximum wins -- all in vector registers, no
-        // ballot -> scalar -> vector round trip in the dependency chain (the rounds are latency-bound).  Two
-        // lanes with EQUAL heads both win, the row then holds more than `want` entries, and the iteration is
-        // redone with the exact rounds below (the first holder wins: ties go to the lower column).  Equal
-        // float32 gains in one row are rare, equal keys inside one lane are already in position order.
         // (no `round < want` test: a row with fewer than k entries runs out of non-zero heads by itself)
-        {
-            unsigned f0 = k0, f1 = k1, f2 = k2, f3 = k3, g0 = q0, g1 = q1, g2 = q2, g3 = q3;
-            for (int round = 0; round < rounds; ++round) {
-                const unsigned M = row16_umax32(f0);
-                const bool win = f0 == M && f0 != 0u;
-                selmask |= win ? (1u << g0) : 0u;
-                f0 = win ? f1 : f0;
-                f1 = win ? f2 : f1;
-                f2 = win ? f3 : f2;
-                f3 = win ? 0u : f3;
-                g0 = win ? g1 : g0;
-                g1 = win ? g2 : g1;
-                g2 = win ? g3 : g2;
-            }
-            // selected entries of this DPP row: 4-step add over its 16 lanes (row16 all-reduce on the max
-            // network works for sums of small counts packed per lane only through a true add; use ballots)
-            int total = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) total += __popc(seg16(__ballot((selmask >> c) & 1u)));
-            if (__ballot(total != want) != 0ull) { // a tie in some row of the wave: the exact rounds decide
-                selmask = 0u;
-                for (int round = 0; round < rounds; ++round) {
-                    const unsigned M = row16_umax32(k0);
-                    const unsigned holders = seg16(__builtin_amdgcn_ballot_w64(k0 == M && k0 != 0u));
-                    const bool win = (holders & (0u - holders)) == my_bit; // lowest holder of this DPP row
-                    selmask |= win ? (1u << q0) : 0u;
-                    k0 = win ? k1 : k0;
-                    k1 = win ? k2 : k1;
-                    k2 = win ? k3 : k2;
-                    k3 = win ? 0u : k3;
-                    q0 = win ? q1 : q0;
-                    q1 = win ? q2 : q1;
-                    q2 = win ? q3 : q2;
-                }
-            }
+        for (int round = 0; round < rounds; ++round) {
+            const unsigned M = row16_umax32(k0);
+            const unsigned holders = seg16(__builtin_amdgcn_ballot_w64(k0 == M && k0 != 0u));
+            const bool win = (holders & (0u - holders)) == my_bit; // lowest holder of this DPP row
+            selmask |= win ? (1u << q0) : 0u;
+            k0 = win ? k1 : k0;
+            k1 = win ? k2 : k1;
+            k2 = win ? k3 : k2;
+            k3 = win ? 0u : k3;
+            q0 = win ? q1 : q0;
+            q1 = win ? q2 : q1;
+            q2 = win ? q3 : q2;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) sel[c] = (selmask >> c) & 1u;

@@ -146,3 +146,64 @@ def add_kwargs_to_signature(func: Callable, func_with_kwargs: Callable, skip: Op
            if p.default != inspect.Parameter.empty and p.name not in skip]
     )
     return func
+
+
+# ---------------------------------------------------------------------------
+# the visiting order's shuffle, faster than numpy but the SAME stream
+# ---------------------------------------------------------------------------
+
+class Pcg64Shuffler:
+    """``rng.shuffle(order)`` of a ``np.random.default_rng`` generator through the library's host routine
+    (``xc_host_shuffle_pcg64``: numpy's own Fisher-Yates walk and PCG64 stream on an int32 array, the swap
+    partners prefetched -- csrc/xc_order.hip).  The generator object is kept in step: after every shuffle its
+    state is what numpy's own shuffle would have left, so mixing both is safe.
+
+    ``Pcg64Shuffler.usable()`` checks the routine against numpy on this machine once (permutation AND the
+    generator's next draws); callers fall back to ``rng.shuffle`` when it says no."""
+
+    _ok = None
+
+    def __init__(self, rng: np.random.Generator, n: int):
+        self.rng, self.n = rng, int(n)
+        self.order = np.arange(self.n, dtype=np.int32)
+
+    @staticmethod
+    def _walk(rng: np.random.Generator, order: np.ndarray) -> None:
+        import ctypes
+
+        from . import _lib
+        st = rng.bit_generator.state
+        s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+        mask = (1 << 64) - 1
+        words = (ctypes.c_uint64 * 4)(s >> 64, s & mask, inc >> 64, inc & mask)
+        has, uint = ctypes.c_int(int(st["has_uint32"])), ctypes.c_uint32(int(st["uinteger"]))
+        _lib.call("xc_host_shuffle_pcg64", ctypes.cast(words, ctypes.c_void_p), ctypes.byref(has), ctypes.byref(uint),
+                  int(order.size), ctypes.c_void_p(order.ctypes.data))
+        st["state"]["state"] = (int(words[0]) << 64) | int(words[1])
+        st["has_uint32"], st["uinteger"] = int(has.value), int(uint.value)
+        rng.bit_generator.state = st
+
+    @classmethod
+    def usable(cls) -> bool:
+        if cls._ok is None:
+            try:
+                ok = True
+                for seed, n in ((13, 1), (7, 2), (123, 1000), (5, 70001)):
+                    a, b = np.random.default_rng(seed), np.random.default_rng(seed)
+                    if type(a.bit_generator).__name__ != "PCG64":
+                        ok = False
+                        break
+                    ref, mine = np.arange(n), np.arange(n, dtype=np.int32)
+                    for _ in range(3):               # cumulative, like the sweeps
+                        a.shuffle(ref)
+                        cls._walk(b, mine)
+                    ok = ok and np.array_equal(ref, mine) and a.integers(0, 1 << 62, size=4).tolist() == b.integers(0, 1 << 62, size=4).tolist()
+                cls._ok = bool(ok)
+            except Exception:
+                cls._ok = False
+        return cls._ok
+
+    def shuffle(self) -> np.ndarray:
+        """Shuffle the int32 order in place (cumulatively) and return it (the caller copies what it keeps)."""
+        self._walk(self.rng, self.order)
+        return self.order
