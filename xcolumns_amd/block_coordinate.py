@@ -20,6 +20,11 @@ reference's signature so call sites stay source-compatible):
 ``bca_parity``     "per_sweep" (default): every sweep's utility within 1e-5 of the sequential reference;
                    "final": wider sweeps, the bar holds for the utility after the last sweep
                    (:class:`WavePolicy`; env XCOLUMNS_BCA_PARITY).
+``bca_deterministic`` True: same `seed` => the same prediction, bit for bit, run to run, with many rows in flight
+                   (block-synchronous sweeps, csrc/xc_bca_det.hip; sparse float32 y_proba; several times the
+                   default sweep's time, still hundreds of times faster than one wavefront; `bca_waves=1` is
+                   deterministic too).  Default False: the faster sweep whose result depends on timing in
+                   a few rows (env XCOLUMNS_BCA_DETERMINISTIC).
 ``bca_diagnostics`` True: ``meta`` also carries "wavefronts" and "rows_changed" per sweep
                    (by default ``meta`` has exactly the reference's keys).
 ``order_backend``  "numpy" (default: the reference's RNG stream, generated on the
@@ -201,7 +206,7 @@ class BcaCsrEngine:
 
     def __init__(self, csr: D.DeviceCSR, k: int, gain_spec: MetricSpec, utility_spec: MetricSpec,
                  maximize: bool = True, skip_tn: bool = False, n_total: Optional[int] = None,
-                 comm=None, use_shadow: Optional[bool] = None):
+                 comm=None, use_shadow: Optional[bool] = None, deterministic: bool = False):
         if k < 1 or k > _lib.XC_MAX_K:
             raise ValueError(f"k must be in 1..{_lib.XC_MAX_K} for sparse y_proba on the GPU, got {k}")
         if csr.n > 0 and csr.min_row_nnz < k:
@@ -212,6 +217,9 @@ class BcaCsrEngine:
                 f"(shortest row has {int(csr.min_row_nnz)})")
         self.csr = csr
         self.k = int(k)
+        # bca_deterministic: concurrent sweeps run block-synchronously (csrc/xc_bca_det.hip): same seed, same bits
+        self.deterministic = bool(deterministic)
+        self._det_ws = None
         self.gain_metric = gain_spec.to_c()
         self.utility_metric = utility_spec.to_c()
         self.maximize = bool(maximize)
@@ -405,6 +413,11 @@ class BcaCsrEngine:
         kernel clears it)."""
         c = self.csr
         full = n_order >= c.n
+        if self.deterministic and int(n_waves) > 1:
+            if not greedy and full and self.can_sweep_deterministic():
+                self.sweep_deterministic(order, n_order, int(n_waves))
+                return
+            n_waves = 1   # greedy first sweep, foreign labels, float64 scores: the sequential sweep is deterministic too
         if not full:
             self.changed.zero_()
         # the packed stream serves the concurrent sweeps (its s is float32); greedy and one-wavefront (exact)
@@ -425,9 +438,44 @@ class BcaCsrEngine:
         if full:
             self.orphans = None
 
+    # -- deterministic concurrent sweep ----------------------------------------------------------------
+    def can_sweep_deterministic(self) -> bool:
+        return self.packed is not None and self.shadow is not None and self.orphans is None
+
+    def sweep_deterministic(self, order: Optional[torch.Tensor], n_order: int, block: int):
+        """One full sweep as blocks of up to `block` rows (xc_bca_det_*): rows of a block are scored on the
+        records as they stood when the block began, changes are settled by integer claims, the boundary
+        statistics are integer sums -- nothing depends on timing.  Leaves the from-scratch statistics in acc."""
+        c = self.csr
+        if self._det_ws is None:
+            nbytes = ctypes.c_int64(0)
+            _lib.call("xc_bca_det_workspace_bytes", int(c.max_row_nnz), c.m, ctypes.byref(nbytes))
+            self._det_ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.dev)
+        if self._pack_dirty:
+            self._repack()
+        block = int(max(2, min(block, 8192)))
+        _lib.call("xc_bca_det_begin", D.ptr(self._det_ws), c.m, D.stream())
+        progress = (ctypes.c_int64 * 2)(0, 0)
+        iters = (n_order + block - 1) // block + 2
+        for _ in range(64):
+            _lib.call("xc_bca_det_blocks", D.ptr(self._det_ws), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
+                      int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta), D.ptr(self.sel), self.k, c.m,
+                      D.ptr(self.shadow), D.ptr(self.packed), ctypes.byref(self.gain_metric), int(self.maximize),
+                      int(self.skip_tn), block, int(iters), progress, D.stream())
+            if progress[0] >= n_order and progress[1] == 0:
+                break
+            iters = max(4, iters // 8)
+        else:
+            raise RuntimeError("deterministic sweep did not finish (rows keep losing their claims)")
+        _lib.call("xc_bca_det_finish", D.ptr(self._det_ws), c.m, D.ptr(self.acc), D.stream())
+        self._acc_filled = True
+        self._partial_sweep = False
+        self._s_entry_dirty = self._s_entry_dirty   # s_entry is untouched; sel / packed were kept in step
+
     # -- the sweep loop without a host round trip per iteration (include/xcolumns_amd.h) --------
     def can_pipeline(self, n_order: int) -> bool:
-        return self.orphans is None and n_order >= self.csr.n and os.environ.get("XCOLUMNS_BCA_PIPELINE", "1") != "0"
+        return (self.orphans is None and n_order >= self.csr.n and not self.deterministic
+                and os.environ.get("XCOLUMNS_BCA_PIPELINE", "1") != "0")
 
     def pipeline_begin(self, old_utility_sum: float, tolerance: float, divisor: float, maximize: bool,
                        policy: "WavePolicy", first_waves: int):
@@ -805,7 +853,7 @@ def _initial_csr_indices(y_proba, init_y_pred, k: int, seed):
 
 def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
             init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves, order_backend,
-            bca_parity=None):
+            bca_parity=None, bca_deterministic=False):
     """Sparse y_proba: a csr_matrix in host memory (uploaded here, result downloaded) or a matrix already
     resident in HBM -- DeviceCSR or torch sparse_csr tensor -- in which case nothing crosses PCIe but the
     visiting orders and the per-sweep utility."""
@@ -823,7 +871,8 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
                 f"(shortest row has {int(row_nnz.min())})")
     dev = D.require_gpu()
     csr = D.as_device_csr(y_proba, dev)
-    eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn)
+    eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
+                       deterministic=bca_deterministic)
 
     log_info("  Initializing initial prediction ...", verbose)
     greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"
@@ -1078,12 +1127,13 @@ def predict_using_bc_with_0approx(
     if bca_parity not in (None, "per_sweep", "final"):
         raise ValueError("bca_parity must be 'per_sweep' or 'final'")
     bca_diagnostics = kwargs.pop("bca_diagnostics", False)
+    bca_deterministic = bool(kwargs.pop("bca_deterministic", os.environ.get("XCOLUMNS_BCA_DETERMINISTIC", "0") == "1"))
     order_backend = kwargs.pop("order_backend", os.environ.get("XCOLUMNS_ORDER_BACKEND", "numpy"))
 
     if is_sparse(y_proba):
         y_pred = _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                          init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves,
-                         order_backend, bca_parity)
+                         order_backend, bca_parity, bca_deterministic)
     else:
         y_pred = _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend,
