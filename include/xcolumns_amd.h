@@ -328,22 +328,22 @@ int xc_bca_set_tuning(double conflict_rel, double hot_unpublished);
 /* ---- deterministic concurrent sweep (csrc/xc_bca_det.hip) --------------------------------------------------------
  * Same `seed` => the same prediction, bit for bit, with many rows in flight: the order is walked in blocks of up to
  * `block` rows (<= 8192); a block scores its rows on the records as they stood when it began, rows claim the labels
- * they want to add or drop with integer atomics, a row commits only if it holds every claim (it is then the single
- * writer of those labels), losers are carried into the next block as its most senior rows; the from-scratch
- * statistics of the boundary are integer (2^-38 fixed point) sums.  float32 scores over the packed row stream
- * (xc_bca_pack_rows*) and the float32 records; no greedy sweep, no orphans.
+ * they want to add or drop (those with fewer than 512 predicted rows) with integer atomics, a row commits only if it
+ * holds every claim, losers are carried into the next block as its most senior rows; the records of the sweep and
+ * the from-scratch statistics of the boundary are integer (2^-38 fixed point) sums.  float32 scores over the packed
+ * row stream (xc_bca_pack_rows*); no greedy sweep, no orphans.
  *   xc_bca_det_workspace_bytes  size of the device workspace for a matrix with rows of <= max_row_nnz entries
- *   xc_bca_det_begin            start a sweep (clears claims, statistics, cursor)
+ *   xc_bca_det_begin            start a sweep (clears claims, statistics, cursor; records <- tpfp[m][2], float64)
  *   xc_bca_det_blocks           run `iterations` blocks; progress_host (optional, blocks on the stream) receives
  *                               {positions of the order consumed, rows of the last block}: the sweep is over when
  *                               all n_order positions are consumed and the last block was empty
  *   xc_bca_det_finish           acc[2m + 1] (float64) <- the sweep's from-scratch {tp, fp} and changed-row count:
  *                               the input of xc_bca_commit_utility */
 int xc_bca_det_workspace_bytes(int max_row_nnz, int64_t m, int64_t *bytes);
-int xc_bca_det_begin(void *workspace, int64_t m, void *stream);
+int xc_bca_det_begin(void *workspace, int64_t m, const double *tpfp, void *stream);
 int xc_bca_det_blocks(void *workspace, int64_t n_order, const int32_t *order, int64_t n_norm,
                       const int32_t *indptr, int max_row_nnz, int32_t *pred_indices, float *pred_eta,
-                      uint8_t *sel, int k, int64_t m, float *shadow, void *packed,
+                      uint8_t *sel, int k, int64_t m, void *packed,
                       const xc_metric *metric_host, int maximize, int skip_tn, int block, int iterations,
                       int64_t *progress_host, void *stream);
 int xc_bca_det_finish(void *workspace, int64_t m, double *acc, void *stream);

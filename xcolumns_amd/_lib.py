@@ -111,9 +111,9 @@ SIGNATURES = {
     "xc_bca_set_validation": (c_int, [c_int]),
     "xc_bca_set_tuning": (c_int, [c_double, c_double]),
     "xc_bca_det_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_int64)]),
-    "xc_bca_det_begin": (c_int, [c_void_p, c_int64, c_void_p]),
+    "xc_bca_det_begin": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "xc_bca_det_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                  c_int, c_int64, c_void_p, c_void_p, POINTER(XcMetric), c_int, c_int, c_int, c_int,
+                                  c_int, c_int64, c_void_p, POINTER(XcMetric), c_int, c_int, c_int, c_int,
                                   POINTER(c_int64), c_void_p]),
     "xc_bca_det_finish": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "xc_host_shuffle_pcg64": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint32), c_int64, c_void_p]),

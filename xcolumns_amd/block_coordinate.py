@@ -440,7 +440,7 @@ class BcaCsrEngine:
 
     # -- deterministic concurrent sweep ----------------------------------------------------------------
     def can_sweep_deterministic(self) -> bool:
-        return self.packed is not None and self.shadow is not None and self.orphans is None
+        return self.packed is not None and self.orphans is None
 
     def sweep_deterministic(self, order: Optional[torch.Tensor], n_order: int, block: int):
         """One full sweep as blocks of up to `block` rows (xc_bca_det_*): rows of a block are scored on the
@@ -454,13 +454,13 @@ class BcaCsrEngine:
         if self._pack_dirty:
             self._repack()
         block = int(max(2, min(block, 8192)))
-        _lib.call("xc_bca_det_begin", D.ptr(self._det_ws), c.m, D.stream())
+        _lib.call("xc_bca_det_begin", D.ptr(self._det_ws), c.m, D.ptr(self.tpfp), D.stream())
         progress = (ctypes.c_int64 * 2)(0, 0)
         iters = (n_order + block - 1) // block + 2
         for _ in range(64):
             _lib.call("xc_bca_det_blocks", D.ptr(self._det_ws), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                       int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta), D.ptr(self.sel), self.k, c.m,
-                      D.ptr(self.shadow), D.ptr(self.packed), ctypes.byref(self.gain_metric), int(self.maximize),
+                      D.ptr(self.packed), ctypes.byref(self.gain_metric), int(self.maximize),
                       int(self.skip_tn), block, int(iters), progress, D.stream())
             if progress[0] >= n_order and progress[1] == 0:
                 break

@@ -14,17 +14,20 @@
 //              BEGAN (nothing writes them during this launch) and takes the top-k -- the arithmetic of the
 //              concurrent sweep.  A row that wants to change labels claims each of them with an integer
 //              atomicMax of (block number, seniority in the block);
-//     commit   a row changes its prediction only if it holds the claim on EVERY label it adds or drops: then no
-//              other row of the block touches those labels, and it is their single writer (plain read-modify-
-//              write, no floating-point atomics).  A row that lost a claim is carried into the next block, where
-//              it is senior to every fresh row -- the oldest row always wins all its claims, so every block makes
-//              progress.
-//   The from-scratch statistics of the sweep boundary (block_coordinate.py:465-467) are accumulated in 2^-38 fixed
-//   point with integer atomics (the sum of integers does not depend on the order of the adds); they agree with
-//   the float64 sums to ~1e-12 relative (a score below 2^-14 is rounded to a multiple of 2^-38).
+//     commit   a row changes its prediction only if it holds EVERY claim it made; a row that lost one is carried
+//              into the next block, where it is senior to every fresh row -- the oldest row always wins all its
+//              claims, so every block makes progress.  Only SMALL labels are claimed (fewer than 512 predicted
+//              rows, the commit protocol's conflict tolerance): a label that sums hundreds of rows cannot be moved
+//              by one row, and on skewed label popularity nearly every row of the first sweep drops the same
+//              head labels -- claiming those would let one row per block through.
+//   During the sweep the per-label records live in 2^-38 FIXED POINT (int64 {tp, fp}): a row's change is an
+//   integer atomicAdd, and a sum of integers does not depend on the order of the adds -- any number of rows may
+//   update a label in one block.  The from-scratch statistics of the sweep boundary (block_coordinate.py:465-467)
+//   are accumulated the same way; they agree with the float64 sums to ~1e-12 relative (a score below 2^-14 is
+//   rounded to a multiple of 2^-38).
 //
 // Nothing in a block depends on timing: the decisions are functions of the frozen records, integer atomicMax /
-// atomicAdd are order-independent, every float value has one writer.  Same seed => same prediction, bit for bit.
+// atomicAdd are order-independent, no floating-point value is accumulated.  Same seed => same prediction, bit for bit.
 // Rows of one block do not see each other's changes (at most B rows of staleness, as in the default sweep) and
 // two rows that want the same label are serialised by the claims (the later one re-decides a block later).
 #include "xc_common.h"
@@ -37,6 +40,7 @@ struct __attribute__((packed, aligned(4))) det_pack3_t {
 };
 #define XC_DET_COL_MASK 0x01ffffffu
 #define XC_DET_FX_SCALE 274877906944.0 /* 2^38 */
+#define XC_DET_SMALL_FX (512ll << 38)  /* tp + fp below this: the label is claimed before it is changed */
 #define XC_DET_MAX_BLOCK 8192
 // state words (int64) of a deterministic sweep
 #define XC_DET_CURSOR 0   /* next position of the order not yet handed to a block */
@@ -54,13 +58,14 @@ struct DetParams {
     int32_t *pred_indices;
     float *pred_eta;
     uint8_t *sel;
-    float *shadow;                 // [m][2] float32 records {tp, fp}
+    long long *rec_fx;             // [m][2] the records {tp, fp} of this sweep in 2^-38 fixed point
     unsigned long long *claim;     // [m]
     long long *acc_fx;             // [2m] fixed-point from-scratch {tp, fp}
     long long *state;              // [XC_DET_WORDS]
     int32_t *blk_rows;             // [2][XC_DET_MAX_BLOCK] row ids of the block (ping-pong)
     uint8_t *blk_retry;            // [2][XC_DET_MAX_BLOCK] 1 = the row lost a claim and is carried
-    unsigned long long *dec_bits;  // [XC_DET_MAX_BLOCK][CH] ballots of the new membership per 64-candidate chunk
+    unsigned long long *dec_bits;  // [XC_DET_MAX_BLOCK][2 * CH] ballots per 64-candidate chunk: the new membership, then
+                                   // the lanes whose label the row claimed
     uint8_t *dec_flag;             // [XC_DET_MAX_BLOCK] 1 = the row wants to change
     int k;
     int block;                     // B
@@ -165,15 +170,18 @@ __global__ __launch_bounds__(XC_BLOCK) void det_decide_kernel(DetParams P) {
     DetRow<CH> cur;
     det_load_row<CH>(P, s0, r, lane, cur);
     unsigned long long key[CH];
+    bool small[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         key[c] = 0ull;
+        small[c] = false;
         if (lane + XC_WAVE * c < r) {
             // the records as they stood when the block began: nothing writes them during this launch
-            const float2 rec = *reinterpret_cast<const float2 *>(P.shadow + (int64_t)cur.idx[c] * 2);
+            const longlong2 rec = *reinterpret_cast<const longlong2 *>(P.rec_fx + (int64_t)cur.idx[c] * 2);
+            small[c] = rec.x + rec.y < XC_DET_SMALL_FX;
             const float e = cur.eta[c];
             const double ed = (double)e, omd = (double)(1.0f - e);
-            double tpc = (double)rec.x, fpc = (double)rec.y;
+            double tpc = (double)rec.x * (1.0 / XC_DET_FX_SCALE), fpc = (double)rec.y * (1.0 / XC_DET_FX_SCALE);
             if (cur.sel[c]) { // statistics without this row (block_coordinate.py:243-246, in registers)
                 tpc -= ed;
                 fpc -= omd;
@@ -233,9 +241,13 @@ __global__ __launch_bounds__(XC_BLOCK) void det_decide_kernel(DetParams P) {
     const unsigned long long mine = ((unsigned long long)P.state[XC_DET_EPOCH] << 16) | (unsigned long long)(65535 - slot);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const unsigned long long bits = __ballot(in_new[c]);
-        if (lane == 0) P.dec_bits[(int64_t)slot * CH + c] = bits;
-        if (changed && in_new[c] != cur.sel[c]) atomicMax(P.claim + cur.idx[c], mine);
+        const bool claims = changed && in_new[c] != cur.sel[c] && small[c];
+        const unsigned long long bits = __ballot(in_new[c]), cbits = __ballot(claims);
+        if (lane == 0) {
+            P.dec_bits[(int64_t)slot * 2 * CH + c] = bits;
+            P.dec_bits[(int64_t)slot * 2 * CH + CH + c] = cbits;
+        }
+        if (claims) atomicMax(P.claim + cur.idx[c], mine);
     }
     if (lane == 0) P.dec_flag[slot] = changed ? 1 : 0;
 }
@@ -259,8 +271,9 @@ __global__ __launch_bounds__(XC_BLOCK) void det_commit_kernel(DetParams P) {
     bool lost = false;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        in_new[c] = (P.dec_bits[(int64_t)slot * CH + c] >> lane) & 1ull;
-        if (changed && in_new[c] != cur.sel[c]) lost = lost || (P.claim[cur.idx[c]] != mine);
+        in_new[c] = (P.dec_bits[(int64_t)slot * 2 * CH + c] >> lane) & 1ull;
+        const bool claimed = (P.dec_bits[(int64_t)slot * 2 * CH + CH + c] >> lane) & 1ull;
+        if (claimed) lost = lost || (P.claim[cur.idx[c]] != mine);
     }
     if (changed && __ballot(lost) != 0ull) { // another row of this block holds one of the labels: decide again next block
         if (lane == 0) P.blk_retry[which * XC_DET_MAX_BLOCK + slot] = 1;
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(XC_BLOCK) void det_commit_kernel(DetParams P) {
             atomicAdd(reinterpret_cast<unsigned long long *>(P.acc_fx) + (int64_t)cur.idx[c] * 2 + 1,
                       (unsigned long long)__double2ll_rn((double)(1.0f - e) * XC_DET_FX_SCALE));
         }
-        // ... and, if it changed, it is the single writer of the labels it adds or drops in this block
+        // ... and, if it changed, its deltas go into the fixed-point records (integer adds: any order, same sum)
         if (changed) {
             const unsigned long long mask = __ballot(in_new[c]);
             if (in_new[c]) {
@@ -287,10 +300,11 @@ __global__ __launch_bounds__(XC_BLOCK) void det_commit_kernel(DetParams P) {
             }
             base += __popcll(mask);
             if (lane + XC_WAVE * c < r && in_new[c] != cur.sel[c]) {
-                const float sgn = in_new[c] ? 1.0f : -1.0f;
-                float *rec = P.shadow + (int64_t)cur.idx[c] * 2;
-                rec[0] = rec[0] + sgn * cur.eta[c];
-                rec[1] = rec[1] + sgn * (1.0f - cur.eta[c]);
+                const long long d_tp = __double2ll_rn((double)cur.eta[c] * XC_DET_FX_SCALE);
+                const long long d_fp = __double2ll_rn((double)(1.0f - cur.eta[c]) * XC_DET_FX_SCALE);
+                unsigned long long *rec = reinterpret_cast<unsigned long long *>(P.rec_fx) + (int64_t)cur.idx[c] * 2;
+                atomicAdd(rec, (unsigned long long)(in_new[c] ? d_tp : -d_tp));
+                atomicAdd(rec + 1, (unsigned long long)(in_new[c] ? d_fp : -d_fp));
                 P.sel[s0 + lane + XC_WAVE * c] = in_new[c] ? 1 : 0;
                 det_pack3_t *e = P.packed + s0 + lane + XC_WAVE * c;
                 e->x = (e->x & 0x7fffffffu) | (in_new[c] ? 0x80000000u : 0u);
@@ -310,8 +324,11 @@ __global__ __launch_bounds__(XC_BLOCK) void det_acc_to_f64_kernel(int64_t m2, lo
     if (blockIdx.x == 0 && threadIdx.x == 0) acc[m2] = (double)state[XC_DET_CHANGED];
 }
 
-__global__ void det_begin_kernel(long long *state) {
-    if (threadIdx.x < XC_DET_WORDS) state[threadIdx.x] = 0;
+__global__ __launch_bounds__(XC_BLOCK) void det_begin_kernel(long long *state, int64_t m2, const double *tpfp, long long *rec_fx) {
+    if (blockIdx.x == 0 && threadIdx.x < XC_DET_WORDS) state[threadIdx.x] = 0;
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; j < m2; j += stride)
+        rec_fx[j] = __double2ll_rn(tpfp[j] * XC_DET_FX_SCALE);
 }
 
 template <int CH>
@@ -331,19 +348,23 @@ extern "C" {
 int xc_bca_det_workspace_bytes(int max_row_nnz, int64_t m, int64_t *bytes) {
     const int ch = xc::chunks_for(max_row_nnz);
     if (!bytes || ch == 0 || m < 1) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_det_workspace_bytes: bad argument");
-    // claim[m] u64 | acc_fx[2m] i64 | state | blk_rows[2][B] | dec_bits[B][CH] | blk_retry[2][B] | dec_flag[B]
-    *bytes = m * 8 + 2 * m * 8 + XC_DET_WORDS * 8 + 2 * XC_DET_MAX_BLOCK * 4 + (int64_t)XC_DET_MAX_BLOCK * ch * 8 +
-             2 * XC_DET_MAX_BLOCK + XC_DET_MAX_BLOCK + 64;
+    // claim[m] u64 | acc_fx[2m] i64 | rec_fx[2m] i64 | state | blk_rows[2][B] | dec_bits[B][2 CH] | blk_retry[2][B] | dec_flag[B]
+    *bytes = m * 8 + 2 * m * 8 + 2 * m * 8 + XC_DET_WORDS * 8 + 2 * XC_DET_MAX_BLOCK * 4 +
+             (int64_t)XC_DET_MAX_BLOCK * 2 * ch * 8 + 2 * XC_DET_MAX_BLOCK + XC_DET_MAX_BLOCK + 64;
     return XC_OK;
 }
 
-// Start a deterministic sweep: clears the claims, the fixed-point statistics and the cursor.
-int xc_bca_det_begin(void *workspace, int64_t m, void *stream) {
-    if (!workspace || m < 1) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_det_begin: bad argument");
+// Start a deterministic sweep: clears the claims, the fixed-point boundary statistics and the cursor, and takes
+// the records of the sweep from the float64 master copy tpfp[m][2] (as the last boundary left it).
+int xc_bca_det_begin(void *workspace, int64_t m, const double *tpfp, void *stream) {
+    if (!workspace || m < 1 || !tpfp) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_det_begin: bad argument");
     hipStream_t st = xc::as_stream(stream);
     char *w = static_cast<char *>(workspace);
     XC_HIP_TRY(hipMemsetAsync(w, 0, (size_t)(m * 8 + 2 * m * 8), st));
-    hipLaunchKernelGGL(xc::det_begin_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<long long *>(w + m * 24));
+    int64_t b = (2 * m + XC_BLOCK - 1) / XC_BLOCK;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(xc::det_begin_kernel, dim3((int)b), dim3(XC_BLOCK), 0, st, reinterpret_cast<long long *>(w + m * 40), 2 * m,
+                       tpfp, reinterpret_cast<long long *>(w + m * 24));
     XC_CHECK_LAUNCH("det_begin_kernel");
     return XC_OK;
 }
@@ -354,9 +375,9 @@ int xc_bca_det_begin(void *workspace, int64_t m, void *stream) {
 // and the last block was empty.
 int xc_bca_det_blocks(void *workspace, int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                       int max_row_nnz, int32_t *pred_indices, float *pred_eta, uint8_t *sel, int k, int64_t m,
-                      float *shadow, void *packed, const xc_metric *metric_host, int maximize, int skip_tn, int block,
+                      void *packed, const xc_metric *metric_host, int maximize, int skip_tn, int block,
                       int iterations, int64_t *progress_host, void *stream) {
-    if (!workspace || n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !shadow ||
+    if (!workspace || n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel ||
         !packed || !metric_host || block < 1 || block > XC_DET_MAX_BLOCK || iterations < 0)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_det_blocks: bad argument");
     if (k < 1 || k > XC_MAX_K) return xc::fail_arg(XC_ERR_K_RANGE, "xc_bca_det_blocks: k=%d outside 1..%d", k, XC_MAX_K);
@@ -374,15 +395,15 @@ int xc_bca_det_blocks(void *workspace, int64_t n_order, const int32_t *order, in
     P.pred_indices = pred_indices;
     P.pred_eta = pred_eta;
     P.sel = sel;
-    P.shadow = shadow;
     P.claim = reinterpret_cast<unsigned long long *>(w);
     P.acc_fx = reinterpret_cast<long long *>(w + m * 8);
-    P.state = reinterpret_cast<long long *>(w + m * 24);
-    char *q = w + m * 24 + XC_DET_WORDS * 8;
+    P.rec_fx = reinterpret_cast<long long *>(w + m * 24);
+    P.state = reinterpret_cast<long long *>(w + m * 40);
+    char *q = w + m * 40 + XC_DET_WORDS * 8;
     P.blk_rows = reinterpret_cast<int32_t *>(q);
     q += 2 * XC_DET_MAX_BLOCK * 4;
     P.dec_bits = reinterpret_cast<unsigned long long *>(q);
-    q += (size_t)XC_DET_MAX_BLOCK * ch * 8;
+    q += (size_t)XC_DET_MAX_BLOCK * 2 * ch * 8;
     P.blk_retry = reinterpret_cast<uint8_t *>(q);
     q += 2 * XC_DET_MAX_BLOCK;
     P.dec_flag = reinterpret_cast<uint8_t *>(q);
@@ -421,7 +442,7 @@ int xc_bca_det_finish(void *workspace, int64_t m, double *acc, void *stream) {
     int64_t b = (2 * m + XC_BLOCK - 1) / XC_BLOCK;
     if (b > 8192) b = 8192;
     hipLaunchKernelGGL(xc::det_acc_to_f64_kernel, dim3((int)b), dim3(XC_BLOCK), 0, xc::as_stream(stream), 2 * m,
-                       reinterpret_cast<long long *>(w + m * 8), acc, reinterpret_cast<long long *>(w + m * 24));
+                       reinterpret_cast<long long *>(w + m * 8), acc, reinterpret_cast<long long *>(w + m * 40));
     XC_CHECK_LAUNCH("det_acc_to_f64_kernel");
     return XC_OK;
 }
