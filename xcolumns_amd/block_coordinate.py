@@ -457,16 +457,21 @@ class BcaCsrEngine:
         _lib.call("xc_bca_det_begin", D.ptr(self._det_ws), c.m, D.ptr(self.tpfp), D.stream())
         progress = (ctypes.c_int64 * 2)(0, 0)
         iters = (n_order + block - 1) // block + 2
-        for _ in range(64):
+        stalled = 0
+        while True:
+            before = (progress[0], progress[1])
             _lib.call("xc_bca_det_blocks", D.ptr(self._det_ws), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                       int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta), D.ptr(self.sel), self.k, c.m,
                       D.ptr(self.packed), ctypes.byref(self.gain_metric), int(self.maximize),
                       int(self.skip_tn), block, int(iters), progress, D.stream())
             if progress[0] >= n_order and progress[1] == 0:
                 break
-            iters = max(4, iters // 8)
-        else:
-            raise RuntimeError("deterministic sweep did not finish (rows keep losing their claims)")
+            # rows that lose a claim take another block: as many more blocks as the rest of the order needs
+            # (the oldest row of a block always wins, so every block settles at least one row)
+            stalled = stalled + 1 if (progress[0], progress[1]) == before else 0
+            if stalled > 64:
+                raise RuntimeError("deterministic sweep makes no progress")
+            iters = max(16, (n_order - int(progress[0]) + block - 1) // block + int(progress[1]) // max(1, block // 4) + 2)
         _lib.call("xc_bca_det_finish", D.ptr(self._det_ws), c.m, D.ptr(self.acc), D.stream())
         self._acc_filled = True
         self._partial_sweep = False
