@@ -355,6 +355,11 @@ int xc_bca_det_finish(void *workspace, int64_t m, double *acc, void *stream);
  * (draws generated a block ahead, the swap partner prefetched). */
 int xc_host_shuffle_pcg64(uint64_t *state_io, int *has_uint32_io, uint32_t *uinteger_io, int64_t n,
                           int32_t *order);
+/* The same walk in two halves, for two host threads: the partners of all n - 1 steps (js[t] belongs to step
+ * i = n-1-t; advances the generator exactly like the shuffle), then the swaps. */
+int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uinteger_io, int64_t n,
+                          uint32_t *js);
+int xc_host_shuffle_apply(int64_t n, const uint32_t *js, int32_t *order);
 
 /* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */

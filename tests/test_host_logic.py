@@ -313,3 +313,14 @@ def test_host_shuffle_is_numpys_stream():
                 mine.order[:] = tmp
                 assert np.array_equal(mine.order, ref)
         assert a.random(3).tolist() == b.random(3).tolist()
+        # the same walk in two halves (draws on one thread, swaps on another: block_coordinate._OrderSource)
+        c, d = np.random.default_rng(seed), np.random.default_rng(seed)
+        if seed % 2:
+            c.integers(0, 100, dtype=np.uint32), d.integers(0, 100, dtype=np.uint32)
+        ref2, halves = np.arange(n), Pcg64Shuffler(d, n)
+        for sweep in range(3):
+            c.shuffle(ref2)
+            js = halves.draws()
+            assert js.dtype == np.uint32 and js.size == max(0, n - 1)
+            assert np.array_equal(halves.apply(js), ref2), (seed, n, sweep)
+        assert c.random(3).tolist() == d.random(3).tolist()

@@ -117,6 +117,8 @@ SIGNATURES = {
                                   POINTER(c_int64), c_void_p]),
     "xc_bca_det_finish": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "xc_host_shuffle_pcg64": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint32), c_int64, c_void_p]),
+    "xc_host_shuffle_draws": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint32), c_int64, c_void_p]),
+    "xc_host_shuffle_apply": (c_int, [c_int64, c_void_p, c_void_p]),
     "xc_event_create": (c_int, [POINTER(c_void_p)]),
     "xc_event_destroy": (c_int, [c_void_p]),
     "xc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_float)]),

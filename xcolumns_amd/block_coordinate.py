@@ -532,6 +532,7 @@ class BcaCsrEngine:
                 order = torch.arange(n, dtype=torch.int32, device=self.dev)
             if getattr(self, "_snap", None) is None:
                 self._snap = torch.empty_like(self.shadow)
+                self._xbuf = torch.empty_like(self.shadow)
             self._snap.copy_(self.shadow)
             bounds = [n * s // segments for s in range(segments + 1)]
             for s in range(segments):
@@ -539,7 +540,7 @@ class BcaCsrEngine:
                           bounds[s + 1] - bounds[s], int(use_packed), int(self._pipe_max_waves), D.ptr(self._ctrl),
                           D.stream())
                 if s < segments - 1:
-                    exchange_changes(self.comm, self.shadow, self._snap)
+                    exchange_changes(self.comm, self.shadow, self._snap, self._xbuf)
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
         slot = j % _lib.XC_CTRL_RING_SLOTS
@@ -642,8 +643,28 @@ class _OrderSource:
             self._q = queue.Queue(maxsize=_ORDER_PREFETCH_DEPTH - 1)
             self._stop = threading.Event()
             self._error = None
+            self._draw_thread = None
+            if self._fast is not None:
+                # two stages: the draws of sweep j + 1 (sequential PCG64 arithmetic, independent of the array) are
+                # generated while the swaps of sweep j are applied (memory-bound) -- both release the GIL in ctypes
+                self._jq = queue.Queue(maxsize=2)
+                self._draw_thread = threading.Thread(target=self._produce_draws, name="xcolumns-order-draws", daemon=True)
+                self._draw_thread.start()
             self._thread = threading.Thread(target=self._produce, name="xcolumns-order", daemon=True)
             self._thread.start()
+
+    def _produce_draws(self):
+        try:
+            while not self._stop.is_set():
+                js = self._fast.draws()
+                while not self._stop.is_set():
+                    try:
+                        self._jq.put(js, timeout=0.05)
+                        break
+                    except Exception:
+                        continue
+        except BaseException as e:
+            self._error = e
 
     def _produce(self):
         try:
@@ -658,7 +679,17 @@ class _OrderSource:
                 if done[slot] is not None:
                     done[slot].synchronize()          # its previous copy has left the pinned buffer
                 if self._fast is not None:
-                    np.copyto(pinned[slot].numpy(), self._fast.shuffle())   # :418-419, int32 walk (GIL released in ctypes)
+                    js = None
+                    while js is None and not self._stop.is_set():
+                        if self._error is not None:
+                            raise self._error
+                        try:
+                            js = self._jq.get(timeout=0.05)
+                        except Exception:
+                            js = None
+                    if js is None:
+                        break
+                    np.copyto(pinned[slot].numpy(), self._fast.apply(js))   # :418-419, the swaps of the int32 walk
                 else:
                     self.rng.shuffle(self.order)      # :418-419 (GIL released)
                     np.copyto(pinned[slot].numpy(), self.order, casting="unsafe")
@@ -710,6 +741,14 @@ class _OrderSource:
                 pass
             self._thread.join(timeout=5.0)
             self._thread = None
+            if getattr(self, "_draw_thread", None) is not None:
+                try:
+                    while True:
+                        self._jq.get_nowait()
+                except Exception:
+                    pass
+                self._draw_thread.join(timeout=5.0)
+                self._draw_thread = None
 
     def __del__(self):
         try:

@@ -126,4 +126,76 @@ int xc_host_shuffle_pcg64(uint64_t *state_io, int *has_uint32_io, uint32_t *uint
     return XC_OK;
 }
 
+// The same walk in two halves, so that the draws of sweep j + 1 (sequential PCG64 arithmetic, independent of the
+// array) can be generated on one host thread while the swaps of sweep j (memory-bound) are applied on another:
+//   xc_host_shuffle_draws  js[t] = the partner of step i = n-1-t, t = 0 .. n-2 (n - 1 entries); advances the generator
+//   xc_host_shuffle_apply  the swaps, in place on the int32 array
+int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uinteger_io, int64_t n, uint32_t *js) {
+    if (!state_io || !has_uint32_io || !uinteger_io || n < 0 || (n > 1 && !js))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_host_shuffle_draws: bad argument");
+    if (n > 0xffffffffLL) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_host_shuffle_draws: n must fit 32 bits");
+    Pcg64 g;
+    g.state = ((u128)state_io[0] << 64) | (u128)state_io[1];
+    g.inc = ((u128)state_io[2] << 64) | (u128)state_io[3];
+    g.has_uint32 = *has_uint32_io;
+    g.uinteger = *uinteger_io;
+    int64_t i = n - 1;
+    uint32_t *out = js;
+    while (i >= 1) {
+        uint64_t mask = (uint64_t)i;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        const int64_t low = (int64_t)(mask >> 1) + 1; // smallest bound with this mask
+        const int64_t cnt = i - low + 1;              // steps i .. low share the mask
+        const uint32_t m32 = (uint32_t)mask;
+        int64_t got = 0;
+        // branch-free filter of the candidate stream, as in xc_host_shuffle_pcg64, two candidates per 64-bit
+        // output (numpy hands out the low half first and buffers the high half: pcg64_next32)
+        if (g.has_uint32 && got < cnt) {
+            g.has_uint32 = 0;
+            const uint32_t v = g.uinteger & m32;
+            out[got] = v;
+            got += (v <= (uint32_t)(i - got)) ? 1 : 0;
+        }
+        while (got < cnt) {
+            const uint64_t w = pcg64_next64(g);
+            const uint32_t v0 = (uint32_t)w & m32;
+            out[got] = v0;
+            got += (v0 <= (uint32_t)(i - got)) ? 1 : 0;
+            if (got < cnt) {
+                const uint32_t v1 = (uint32_t)(w >> 32) & m32;
+                out[got] = v1;
+                got += (v1 <= (uint32_t)(i - got)) ? 1 : 0;
+            } else { // the run ended on the low half: the high half stays buffered for the next draw
+                g.has_uint32 = 1;
+                g.uinteger = (uint32_t)(w >> 32);
+            }
+        }
+        out += cnt;
+        i -= cnt;
+    }
+    state_io[0] = (uint64_t)(g.state >> 64);
+    state_io[1] = (uint64_t)g.state;
+    *has_uint32_io = g.has_uint32;
+    *uinteger_io = g.uinteger;
+    return XC_OK;
+}
+
+int xc_host_shuffle_apply(int64_t n, const uint32_t *js, int32_t *order) {
+    if (n < 0 || (n > 1 && (!js || !order))) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_host_shuffle_apply: bad argument");
+    const int64_t steps = n - 1;
+    for (int64_t t = 0; t < steps; ++t) {
+        if (t + 32 < steps) __builtin_prefetch(order + js[t + 32], 1, 0);
+        const int64_t a = n - 1 - t;
+        const uint32_t j = js[t];
+        const int32_t tmp = order[j];
+        order[j] = order[a];
+        order[a] = tmp;
+    }
+    return XC_OK;
+}
+
 } // extern "C"

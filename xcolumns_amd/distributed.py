@@ -71,15 +71,18 @@ class TorchComm:
         return t
 
 
-def exchange_changes(comm: "TorchComm", records: torch.Tensor, snapshot: torch.Tensor) -> None:
+def exchange_changes(comm: "TorchComm", records: torch.Tensor, snapshot: torch.Tensor,
+                     buf: Optional[torch.Tensor] = None) -> None:
     """Mid-sweep exchange between row shards: every rank publishes what ITS rows changed in the
     replicated per-label `records` since `snapshot` was taken and takes in the other ranks' changes
     (one all-reduce of the difference), in place; `snapshot` is left equal to the merged records.
-    Works on any device (the GPU engine passes its float32 records, the CPU tests a float64 table)."""
-    mine = records - snapshot
-    everyone = mine.clone()
-    comm.all_reduce(everyone)
-    records += everyone - mine
+    Works on any device (the GPU engine passes its float32 records, the CPU tests a float64 table).
+    Nothing else touches `records` between the three steps (the sweep waits for the exchange), so the merged
+    records are simply snapshot + sum over ranks of (records - snapshot): three element-wise passes, no
+    temporaries when `buf` (same shape) is given."""
+    buf = torch.sub(records, snapshot, out=buf)       # what my rows changed
+    comm.all_reduce(buf)                              # what everybody's rows changed
+    torch.add(snapshot, buf, out=records)
     snapshot.copy_(records)
 
 

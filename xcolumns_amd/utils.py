@@ -207,3 +207,31 @@ class Pcg64Shuffler:
         """Shuffle the int32 order in place (cumulatively) and return it (the caller copies what it keeps)."""
         self._walk(self.rng, self.order)
         return self.order
+
+    # the two halves of the walk, for two threads (block_coordinate._OrderSource): the draws of sweep j + 1 do not
+    # depend on the array, so they are generated while the swaps of sweep j are applied
+    def draws(self) -> np.ndarray:
+        """The swap partners of the NEXT shuffle (uint32[n - 1]); advances the generator like the shuffle itself."""
+        import ctypes
+
+        from . import _lib
+        js = np.empty(max(0, self.n - 1), dtype=np.uint32)
+        st = self.rng.bit_generator.state
+        s_, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+        mask = (1 << 64) - 1
+        words = (ctypes.c_uint64 * 4)(s_ >> 64, s_ & mask, inc >> 64, inc & mask)
+        has, uint = ctypes.c_int(int(st["has_uint32"])), ctypes.c_uint32(int(st["uinteger"]))
+        _lib.call("xc_host_shuffle_draws", ctypes.cast(words, ctypes.c_void_p), ctypes.byref(has), ctypes.byref(uint),
+                  self.n, ctypes.c_void_p(js.ctypes.data))
+        st["state"]["state"] = (int(words[0]) << 64) | int(words[1])
+        st["has_uint32"], st["uinteger"] = int(has.value), int(uint.value)
+        self.rng.bit_generator.state = st
+        return js
+
+    def apply(self, js: np.ndarray) -> np.ndarray:
+        """Apply the swaps of one shuffle to the order (in place) and return it."""
+        import ctypes
+
+        from . import _lib
+        _lib.call("xc_host_shuffle_apply", self.n, ctypes.c_void_p(js.ctypes.data), ctypes.c_void_p(self.order.ctypes.data))
+        return self.order
