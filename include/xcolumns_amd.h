@@ -361,6 +361,14 @@ int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uint
                           uint32_t *js);
 int xc_host_shuffle_apply(int64_t n, const uint32_t *js, int32_t *order);
 
+/* Row shards, overlapped mid-sweep exchange (xcolumns_amd/block_coordinate.py:pipeline_step): one element-wise step
+ * over the n = 2m float32 record values.  fold != 0: first take in the other ranks' part of the exchange issued one
+ * step earlier (records += sum - mine, base likewise; `sum` = the all-reduced changes, `mine` = this rank's share
+ * of them).  Then publish: mine = sum = records - base (what this rank's rows changed since its last publication),
+ * base = records.  The caller starts an asynchronous all-reduce on `sum` and lets the next segment of the sweep run. */
+int xc_bca_exchange_step(int64_t n, float *records, float *base, float *sum, float *mine, int fold,
+                         void *stream);
+
 /* Unpack the per-label statistics into the reference's four vectors
  * (tp, fp, fn, tn: float64[m]); tn = -1 when skip_tn. */
 int xc_bca_state_unpack(int64_t m, const double *tpfp, const double *colsum,

@@ -53,5 +53,18 @@ def test_sharded_bca_two_exchanges_per_sweep():
     assert abs(got[0] - ref[0]) < 1.5e-4 and abs(got[-1] - ref[-1]) < 2e-6
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_sharded_bca_default_exchange_schedule(overlap):
+    """The default (bca_exchanges="auto") with the real GPU engine on two ranks: the overlapped form (the exchange of
+    part p is folded in after part p + 1, the all-reduce runs beside the sweep) and the blocking form both end
+    within 1e-5 of the sequential oracle after the same 6 sweeps and never let the utility fall."""
+    out = _run("bca_sharded_rehearsal.py", {"XCOLUMNS_BCA_EXCHANGE_OVERLAP": overlap})
+    got, ref = _traces(out)
+    d = [abs(a - b) for a, b in zip(got, ref)]
+    print("two shards, default schedule, overlap =", overlap, re.search(r"^exchanges.*$", out, re.M).group(0), "diff per sweep", d)
+    assert len(got) == len(ref) and d[-1] < 1e-5 and d[0] < 2e-4
+    assert all(b > a - 1e-6 for a, b in zip(got, got[1:]))
+
+
 def test_sharded_frank_wolfe_two_ranks_one_gpu():
     assert "sharded == single process: True" in _run("fw_sharded_rehearsal.py")

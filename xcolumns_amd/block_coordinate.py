@@ -533,14 +533,33 @@ class BcaCsrEngine:
             if getattr(self, "_snap", None) is None:
                 self._snap = torch.empty_like(self.shadow)
                 self._xbuf = torch.empty_like(self.shadow)
+                self._xmine = torch.empty_like(self.shadow)
             self._snap.copy_(self.shadow)
-            bounds = [n * s // segments for s in range(segments + 1)]
-            for s in range(segments):
+            # Overlapped form (default; XCOLUMNS_BCA_EXCHANGE_OVERLAP=0 = the blocking form): twice as many parts,
+            # and what the ranks publish at the end of part p is folded in at the end of part p + 1 -- the
+            # all-reduce runs beside part p + 1 instead of in front of it, and one fused element-wise pass
+            # (xc_bca_exchange_step) replaces the three of the blocking form.  A rank then misses the others' updates
+            # of 1/2 .. 1 blocking segments (blocking: 0 .. 1): about the same staleness, no waiting.
+            overlap = (os.environ.get("XCOLUMNS_BCA_EXCHANGE_OVERLAP", "1") != "0" and hasattr(self.comm, "all_reduce_async"))
+            parts = min(2 * segments, 16, max(1, n)) if overlap else segments
+            self.exchanges_used[-1] = parts
+            bounds = [n * s // parts for s in range(parts + 1)]
+            pending = None
+            for s in range(parts):
                 _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), bounds[s],
                           bounds[s + 1] - bounds[s], int(use_packed), int(self._pipe_max_waves), D.ptr(self._ctrl),
                           D.stream())
-                if s < segments - 1:
-                    exchange_changes(self.comm, self.shadow, self._snap, self._xbuf)
+                if s < parts - 1:
+                    if not overlap:
+                        exchange_changes(self.comm, self.shadow, self._snap, self._xbuf)
+                        continue
+                    if pending is not None:
+                        pending.wait()
+                    _lib.call("xc_bca_exchange_step", 2 * self.csr.m, D.ptr(self.shadow), D.ptr(self._snap), D.ptr(self._xbuf),
+                              D.ptr(self._xmine), int(pending is not None), D.stream())
+                    pending = self.comm.all_reduce_async(self._xbuf)
+            if pending is not None:
+                pending.wait()   # the last publication is superseded by the boundary's from-scratch statistics
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
         slot = j % _lib.XC_CTRL_RING_SLOTS

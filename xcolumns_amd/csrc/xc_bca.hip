@@ -992,6 +992,29 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
     tn[j] = skip_tn ? -1.0 : (n_counted - tpfp[2 * j + 1] - colsum[j]);
 }
 
+// ---- row shards: one step of the overlapped mid-sweep exchange ----------------------------------------------
+// `records` (float32) is this rank's working copy of the per-label records, `base` the same without the rank's own
+// not-yet-published changes.  A step (a) folds in the OTHER ranks' part of the exchange issued one step earlier
+// (`sum` = all-reduced changes, `mine` = this rank's contribution to it), then (b) publishes what this rank's rows
+// changed since: it leaves it in `mine` and in `sum` (the buffer the next all-reduce runs on) and moves `base` up.
+__global__ __launch_bounds__(XC_BLOCK) void exchange_step_kernel(int64_t n, float *records, float *base, float *sum,
+                                                                 float *mine, int fold) {
+    const int64_t stride = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; i < n; i += stride) {
+        float r = records[i], b = base[i];
+        if (fold) {
+            const float others = sum[i] - mine[i];
+            r += others;
+            b += others;
+        }
+        const float own = r - b; // what this rank's rows changed since its last publication
+        records[i] = r;
+        base[i] = r;
+        mine[i] = own;
+        sum[i] = own;
+    }
+}
+
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
 // one-shot HIP events recorded tightly around the NEXT sweep launch (xc_bca_time_next_sweep)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
@@ -1447,6 +1470,16 @@ int xc_host_alloc_pinned(void **ptr, int64_t bytes) {
 
 int xc_host_free_pinned(void *ptr) {
     if (ptr) XC_HIP_TRY(hipHostFree(ptr));
+    return XC_OK;
+}
+
+int xc_bca_exchange_step(int64_t n, float *records, float *base, float *sum, float *mine, int fold, void *stream) {
+    if (n < 0 || (n > 0 && (!records || !base || !sum || !mine)))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_exchange_step: bad argument");
+    if (n == 0) return XC_OK;
+    hipLaunchKernelGGL(xc::exchange_step_kernel, dim3(xc::grid_for(n)), dim3(XC_BLOCK), 0, xc::as_stream(stream), n, records,
+                       base, sum, mine, fold);
+    XC_CHECK_LAUNCH("exchange_step_kernel");
     return XC_OK;
 }
 

@@ -63,12 +63,29 @@ class TorchComm:
         torch.cuda.synchronize()
         return float(sum(a.elapsed_time(b) for a, b in pairs))
 
+    def all_reduce_async(self, t: torch.Tensor):
+        """Start a sum all-reduce of `t` and return at once; ``.wait()`` on the returned handle orders the
+        current stream (RCCL) / the host (gloo) behind its completion.  The overlapped mid-sweep exchange
+        (block_coordinate.BcaCsrEngine.pipeline_step) runs the next segment of the sweep meanwhile."""
+        self.bytes_reduced += t.numel() * t.element_size()
+        self.calls += 1
+        if self.world > 1:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return _Done()
+
     def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
         """Control-plane reduction (argument checks that every rank must agree on); not counted
         as data-path traffic."""
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
+
+
+class _Done:
+    """Handle of a collective that needed no communication (one rank)."""
+
+    def wait(self):
+        return True
 
 
 def exchange_changes(comm: "TorchComm", records: torch.Tensor, snapshot: torch.Tensor,
