@@ -141,6 +141,12 @@ int xc_topk_dense(int64_t n, int64_t m, int64_t ld, const void *gains, int gdtyp
                   int k, double th, int keep_scores, void *y_pred, int pdtype,
                   void *stream);
 
+/* A dense 0/1 prediction with k ones per row (xc_topk_dense's output) as k column ids per row, ascending, and --
+ * when out_val is given -- the entries of `gains` (n x m, row-contiguous) at those columns: the fixed-width CSR
+ * form.  experiments/utils.py:198-210 (load_npy_full_pred: dense scores -> top-k CSR) rests on it. */
+int xc_dense_pred_to_fixed(int64_t n, int64_t m, const void *y_pred, int pdtype, const void *gains,
+                           int gdtype, int k, int32_t *out_idx, void *out_val, void *stream);
+
 /* ---- confusion matrix ---------------------------------------------------- */
 
 /* calculate_confusion_matrix, CSR branch, axis 0 (confusion_matrix.py:364-399 ->
@@ -360,6 +366,12 @@ int xc_host_shuffle_pcg64(uint64_t *state_io, int *has_uint32_io, uint32_t *uint
 int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uinteger_io, int64_t n,
                           uint32_t *js);
 int xc_host_shuffle_apply(int64_t n, const uint32_t *js, int32_t *order);
+
+/* Busy labels: counts[m] <- how often each label occurs among every `stride`-th stored entry (indices[0], indices[stride],
+ * ...), then list <- (label, sampled count) pairs of the labels with sampled count >= min_count, at most `cap` of
+ * them, in arrival order; *n_list <- how many reached the threshold.  The engine picks its <= 63 hot labels from it. */
+int xc_label_busy_list(int64_t nnz, const int32_t *indices, int64_t stride, int64_t m, int min_count, int cap,
+                       int32_t *counts, int32_t *list, int32_t *n_list, void *stream);
 
 /* Row shards, overlapped mid-sweep exchange (xcolumns_amd/block_coordinate.py:pipeline_step): one element-wise step
  * over the n = 2m float32 record values.  fold != 0: first take in the other ranks' part of the exchange issued one

@@ -255,18 +255,29 @@ class BcaCsrEngine:
             # stored in n / 32 rows shows up thousands of times in it, and the hot set only steers how the
             # kernel batches its atomics -- not worth a full histogram of the matrix (2.1 ms at 1M x 500K)
             stride = max(1, csr.nnz // (1 << 22))
-            counts = torch.bincount(csr.indices[::stride], minlength=m) * stride
-            top = torch.topk(counts, min(63, m))
             # "hot" presumes a record that sums so many rows that a few rows' delay cannot move a gain: at
             # least 4096 stored entries (a label stored in 500 of 6000 rows is busy, but its tp is ~10)
-            keep = top.values >= max(4096, csr.n // 32)
-            n_hot, n_busy = (int(x) for x in torch.stack([keep.sum(), (top.values >= max(64, csr.n // 32)).sum()]).tolist())
-            self.skewed = n_busy > 0
+            busy_min, hot_min = max(64, csr.n // 32), max(4096, csr.n // 32)
+            # at most 32 * (entries per row) labels can be stored in n / 32 rows each; sampling noise on top
+            cap = int(min(m, 40 * (csr.nnz // max(1, csr.n) + 1) + 64))
+            counts = torch.empty(m, dtype=torch.int32, device=dev)
+            found = torch.empty(2 * cap + 1, dtype=torch.int32, device=dev)
+            _lib.call("xc_label_busy_list", csr.nnz, D.ptr(csr.indices), stride, m, max(1, busy_min // stride), cap,
+                      D.ptr(counts), D.ptr(found[1:]), D.ptr(found[:1]), D.stream())
+            found = found.cpu().numpy()
+            n_found = min(int(found[0]), cap)
+            pairs = found[1:1 + 2 * n_found].reshape(n_found, 2).astype(np.int64)
+            pairs[:, 1] *= stride
+            # most frequent first, ties by label id: the same table whatever order the kernel listed them in
+            pairs = pairs[np.lexsort((pairs[:, 0], -pairs[:, 1]))]
+            self.skewed = n_found > 0
+            hot = pairs[pairs[:, 1] >= hot_min][:63]
+            n_hot = int(hot.shape[0])
+            labels = torch.from_numpy(hot[:, 0].astype(np.int32)).to(dev)
             if not (self.packed is not None and self.shadow is not None
                     and os.environ.get("XCOLUMNS_BCA_HOT", "1") != "0"):
                 n_hot = 0
             if n_hot > 0:
-                labels = top.indices[:n_hot].to(torch.int32)
                 self.hot_labels = torch.full((64,), -1, dtype=torch.int32, device=dev)
                 self.hot_labels[1:n_hot + 1] = labels
                 self.hot_slot = torch.zeros(m, dtype=torch.uint8, device=dev)

@@ -992,6 +992,29 @@ __global__ __launch_bounds__(XC_BLOCK) void state_unpack_kernel(int64_t m, const
     tn[j] = skip_tn ? -1.0 : (n_counted - tpfp[2 * j + 1] - colsum[j]);
 }
 
+// ---- which labels are busy (stored in many rows)?  a strided sample of the stored entries is enough ----------
+__global__ __launch_bounds__(XC_BLOCK) void label_hist_sampled_kernel(int64_t n_samples, int64_t stride, const int32_t *indices,
+                                                                      int32_t *counts) {
+    const int64_t step = (int64_t)gridDim.x * XC_BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; t < n_samples; t += step)
+        atomicAdd(counts + indices[t * stride], 1);
+}
+
+// labels whose sampled count reaches `min_count`, as (label, count) pairs in arrival order (the caller sorts the few)
+__global__ __launch_bounds__(XC_BLOCK) void label_busy_list_kernel(int64_t m, const int32_t *counts, int min_count, int cap,
+                                                                   int32_t *list, int32_t *n_list) {
+    const int64_t j = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const int c = counts[j];
+    if (c >= min_count) {
+        const int o = atomicAdd(n_list, 1);
+        if (o < cap) {
+            list[2 * o] = (int32_t)j;
+            list[2 * o + 1] = c;
+        }
+    }
+}
+
 // ---- row shards: one step of the overlapped mid-sweep exchange ----------------------------------------------
 // `records` (float32) is this rank's working copy of the per-label records, `base` the same without the rank's own
 // not-yet-published changes.  A step (a) folds in the OTHER ranks' part of the exchange issued one step earlier
@@ -1470,6 +1493,23 @@ int xc_host_alloc_pinned(void **ptr, int64_t bytes) {
 
 int xc_host_free_pinned(void *ptr) {
     if (ptr) XC_HIP_TRY(hipHostFree(ptr));
+    return XC_OK;
+}
+
+int xc_label_busy_list(int64_t nnz, const int32_t *indices, int64_t stride, int64_t m, int min_count, int cap,
+                       int32_t *counts, int32_t *list, int32_t *n_list, void *stream) {
+    if (nnz < 0 || stride < 1 || m < 1 || cap < 1 || (nnz > 0 && !indices) || !counts || !list || !n_list)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_label_busy_list: bad argument");
+    hipStream_t st = xc::as_stream(stream);
+    XC_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)m * 4, st));
+    XC_HIP_TRY(hipMemsetAsync(n_list, 0, 4, st));
+    const int64_t n_samples = nnz / stride;
+    if (n_samples > 0)
+        hipLaunchKernelGGL(xc::label_hist_sampled_kernel, dim3(xc::grid_for(n_samples)), dim3(XC_BLOCK), 0, st, n_samples, stride,
+                           indices, counts);
+    hipLaunchKernelGGL(xc::label_busy_list_kernel, dim3((unsigned)((m + XC_BLOCK - 1) / XC_BLOCK)), dim3(XC_BLOCK), 0, st, m,
+                       counts, min_count, cap, list, n_list);
+    XC_CHECK_LAUNCH("label_busy_list_kernel");
     return XC_OK;
 }
 

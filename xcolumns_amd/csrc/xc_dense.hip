@@ -515,9 +515,58 @@ __global__ __launch_bounds__(XC_DENSE_BLOCK) void bca_sweep_dense_conc_kernel(De
     if (threadIdx.x == 0 && n_changed && changed) atomicAdd(changed, n_changed);
 }
 
+// ---- a 0/1 prediction with exactly k ones per row -> k column ids per row (ascending) and the scores there ----
+// one wavefront per row; ballot / popcount compaction in column order
+template <typename P, typename G>
+__global__ __launch_bounds__(XC_BLOCK) void dense_pred_to_fixed_kernel(int64_t n, int64_t m, int64_t ld_pred, const P *y_pred,
+                                                                       int64_t ld_gain, const G *gains, int k,
+                                                                       int32_t *out_idx, G *out_val) {
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const P *p = y_pred + row * ld_pred;
+    int base = 0;
+    for (int64_t j0 = 0; j0 < m && base < k; j0 += XC_WAVE) {
+        const int64_t j = j0 + lane;
+        const bool on = j < m && p[j] != (P)0;
+        const unsigned long long mask = __ballot(on);
+        const int slot = base + __popcll(mask & lanemask_lt());
+        if (on && slot < k) {
+            out_idx[row * k + slot] = (int32_t)j;
+            if (out_val) out_val[row * k + slot] = gains[row * ld_gain + j];
+        }
+        base += __popcll(mask);
+    }
+    for (int q = base + lane; q < k; q += XC_WAVE) { // fewer than k ones (m < k): pad like the CSR top-k does
+        out_idx[row * k + q] = 0;
+        if (out_val) out_val[row * k + q] = (G)0;
+    }
+}
+
 } // namespace xc
 
 extern "C" {
+
+int xc_dense_pred_to_fixed(int64_t n, int64_t m, const void *y_pred, int pdtype, const void *gains, int gdtype, int k,
+                           int32_t *out_idx, void *out_val, void *stream) {
+    if (n < 0 || m < 0 || k < 1 || (n * m > 0 && (!y_pred || !out_idx)) || (out_val && !gains))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_dense_pred_to_fixed: bad argument");
+    if ((pdtype != XC_F32 && pdtype != XC_F64) || (gdtype != XC_F32 && gdtype != XC_F64))
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_dense_pred_to_fixed: unknown dtype");
+    if (n == 0) return XC_OK;
+    hipStream_t st = xc::as_stream(stream);
+    dim3 grid((unsigned)((n + 3) / 4)), block(XC_BLOCK);
+#define XC_P2F(PT, GT)                                                                                                   \
+    hipLaunchKernelGGL((xc::dense_pred_to_fixed_kernel<PT, GT>), grid, block, 0, st, n, m, m, static_cast<const PT *>(y_pred), \
+                       m, static_cast<const GT *>(gains), k, out_idx, static_cast<GT *>(out_val))
+    if (pdtype == XC_F32 && gdtype == XC_F32) XC_P2F(float, float);
+    else if (pdtype == XC_F32) XC_P2F(float, double);
+    else if (gdtype == XC_F32) XC_P2F(double, float);
+    else XC_P2F(double, double);
+#undef XC_P2F
+    XC_CHECK_LAUNCH("dense_pred_to_fixed_kernel");
+    return XC_OK;
+}
 
 int xc_topk_dense(int64_t n, int64_t m, int64_t ld, const void *gains, int gdtype, int k, double th,
                   int keep_scores, void *y_pred, int pdtype, void *stream) {

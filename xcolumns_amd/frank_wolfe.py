@@ -171,7 +171,12 @@ class FwEngine:
             self._counts_path = bool(self.k > 0 and self.n > 0 and row_nnz.min() >= self.k
                                      and bool((self.true.data == 1).all().item()) and yt.has_sorted_indices)
             if self._counts_path:
-                self._true_count = torch.bincount(self.true.indices, minlength=self.m).to(torch.float64)
+                # rows per label of y_true (xc_label_busy_list with stride 1 leaves the full histogram in `counts`)
+                counts = torch.empty(self.m, dtype=torch.int32, device=self.dev)
+                scratch = torch.empty(4, dtype=torch.int32, device=self.dev)
+                _lib.call("xc_label_busy_list", self.true.nnz, D.ptr(self.true.indices), 1, self.m, 2 ** 31 - 1, 1,
+                          D.ptr(counts), D.ptr(scratch[1:]), D.ptr(scratch[:1]), D.stream())
+                self._true_count = counts.to(torch.float64)
         else:
             yt = y_true if isinstance(y_true, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_true))
             yp = y_proba if isinstance(y_proba, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_proba))

@@ -99,9 +99,22 @@ def load_npy_full_pred(path: str, keep_top_k: int = 0, **kwargs) -> csr_matrix:
                                     np.zeros(n + 1, dtype=np.int32), dtype=np.float32, shape=dense.shape,
                                     sort_indices=True)
     dev = D.require_gpu()
-    vals, idx = torch.topk(torch.from_numpy(np.ascontiguousarray(dense)).to(dev), keep_top_k, dim=1)
+    from . import _lib
+    from .weighted_prediction import topk_dense_device
+    scores = torch.from_numpy(np.ascontiguousarray(dense)).to(dev)
+    if scores.dtype not in (torch.float32, torch.float64):
+        scores = scores.to(torch.float32)
+    m = scores.shape[1]
+    if keep_top_k > m:
+        raise ValueError(f"keep_top_k={keep_top_k} exceeds the number of columns {m}")
+    # the package's own row top-k (xc_topk_dense: ties go to the lower column) and a compaction of its 0/1 rows
+    y_pred = topk_dense_device(scores, keep_top_k, 0.0, False, scores.dtype)
+    idx = torch.empty(n * keep_top_k, dtype=torch.int32, device=dev)
+    vals = torch.empty(n * keep_top_k, dtype=scores.dtype, device=dev)
+    _lib.call("xc_dense_pred_to_fixed", n, m, D.ptr(y_pred), D.dtype_code(y_pred.dtype), D.ptr(scores),
+              D.dtype_code(scores.dtype), int(keep_top_k), D.ptr(idx), D.ptr(vals), D.stream())
     indptr = np.arange(0, n + 1, 1, dtype=np.int32) * keep_top_k
-    return construct_csr_matrix(vals.cpu().numpy().flatten(), idx.cpu().numpy().flatten(), indptr, dtype=np.float32,
+    return construct_csr_matrix(vals.cpu().numpy(), idx.cpu().numpy().astype(np.int64), indptr, dtype=np.float32,
                                 sort_indices=True)
 
 
