@@ -188,6 +188,11 @@ typedef unsigned int uint4q_t __attribute__((ext_vector_type(4)));
 #define XC_Q4_RSRC_WORD3 0x00020000 /* raw buffer, 32-bit data format (gfx9) */
 #define XC_Q4_CPOL_NT 2             /* streaming loads: do not keep the lines */
 
+// Template flags turn the optional features into straight-line code (the kernel is instruction-bound: ~1300 issue
+// cycles per four rows with every feature behind a run-time branch): WMODE 0 = no weights, 1 = interleaved (a, b) pairs,
+// 2 = separate a and / or b (with per-row classifier offsets when CLS); EXTRA = eta and membership flags are written too
+// (the BCA initial prediction).
+template <int WMODE, bool CLS, bool EXTRA>
 __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float> P) {
     const int lane = lane_id();
     const int l16 = lane & 15;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         load(s1, nxt);
         rc = clampr(row + 2 * G);
         const int s2 = P.indptr[rc], e2 = P.indptr[rc + 1];
-        const int64_t w_off = (P.row_cls && live) ? (int64_t)P.row_cls[row] * P.ld : 0;
+        const int64_t w_off = (CLS && live) ? (int64_t)P.row_cls[row] * P.ld : 0;
 
         int idx[4];
         float eta[4], gain[4];
@@ -242,14 +247,16 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
             idx[c] = valid ? (int)cur.idx[c] : 0;
             eta[c] = __uint_as_float(cur.eta[c]);
             float g = eta[c];
-            if (P.ab) {
+            if (WMODE == 1) {
                 typedef float pair_t __attribute__((ext_vector_type(2)));
                 const pair_t w = *reinterpret_cast<const pair_t *>(P.ab + 2 * (int64_t)idx[c]);
                 g = g * w.x; // numba_csr_functions.py:608-609
                 g = g + w.y; // :610-611
             }
-            if (P.a) g = g * P.a[w_off + idx[c]];
-            if (P.b) g = g + P.b[w_off + idx[c]];
+            if (WMODE == 2) {
+                if (P.a) g = g * P.a[w_off + idx[c]];
+                if (P.b) g = g + P.b[w_off + idx[c]];
+            }
             gain[c] = g;
             key[c] = valid ? sortable_key32(nan_to_neg_inf(g)) : 0u;
             sel[c] = false;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         // ascending-column emission inside the DPP row: positions are lane-major
         int32_t *o_idx = P.out_indices + row * k;
         float *o_dat = P.out_data ? P.out_data + row * k : nullptr;
-        float *o_eta = P.out_eta ? P.out_eta + row * k : nullptr;
+        float *o_eta = (EXTRA && P.out_eta) ? P.out_eta + row * k : nullptr;
         // selected entries held by the lower lanes of the DPP row, from the per-entry ballots
         int before = 0;
 #pragma unroll
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
                 if (o_eta) o_eta[slot] = eta[c];
             }
             slot += sel[c] ? 1 : 0;
-            if (P.out_sel && live && 4 * l16 + c < r) P.out_sel[s + 4 * l16 + c] = sel[c] ? 1 : 0;
+            if (EXTRA && P.out_sel && live && 4 * l16 + c < r) P.out_sel[s + 4 * l16 + c] = sel[c] ? 1 : 0;
         }
         // :599-601: slots a short row leaves unused keep column 0 / value 1
         if (live)
@@ -441,7 +448,24 @@ static int launch_topk_q4(int64_t n, const int32_t *indptr, const int32_t *indic
     P.out_eta = static_cast<float *>(out_eta);
     P.out_sel = out_sel;
     P.n_waves = default_row_waves((n + 3) / 4);
-    hipLaunchKernelGGL(topk_csr_q4_kernel, dim3((P.n_waves + 3) / 4), dim3(XC_BLOCK), 0, st, P);
+    const dim3 grid((P.n_waves + 3) / 4), block(XC_BLOCK);
+    const int wmode = P.ab ? 1 : ((P.a || P.b) ? 2 : 0);
+    const bool extra = P.out_eta || P.out_sel;
+#define XC_Q4(W, C, E) hipLaunchKernelGGL((topk_csr_q4_kernel<W, C, E>), grid, block, 0, st, P)
+    if (wmode == 0) {
+        if (extra) XC_Q4(0, false, true);
+        else XC_Q4(0, false, false);
+    } else if (wmode == 1) {
+        if (extra) XC_Q4(1, false, true);
+        else XC_Q4(1, false, false);
+    } else if (P.row_cls) {
+        if (extra) XC_Q4(2, true, true);
+        else XC_Q4(2, true, false);
+    } else {
+        if (extra) XC_Q4(2, false, true);
+        else XC_Q4(2, false, false);
+    }
+#undef XC_Q4
     return 0;
 }
 
