@@ -347,17 +347,22 @@ def worker(args):
     extras = not args.no_extras and world == 1
 
     parity = args.parity or os.environ.get("XCOLUMNS_BCA_PARITY", "per_sweep")
+    matrices = {}
 
     def build(scaling, zipf, use_shadow=None, packed=True, parity=parity):
         """(engine, policy, orders, local rows, global rows, host matrix) of this rank for one mode."""
         n_global = n * world if scaling == "weak" else n
         lo, hi = shard_bounds(n_global, world, rank)
-        if scaling == "weak":
-            # rank r holds the whole n-row workload matrix, generated from its own seeds
-            Y = make_csr_rows(n, m, 0, n, R_NNZ, seed=MATRIX_SEED + 8 * rank, zipf=zipf, k=K)
-        else:
-            Y = make_csr_rows(n, m, lo, hi, R_NNZ, seed=MATRIX_SEED, zipf=zipf, k=K)
-        csr = D.DeviceCSR.from_scipy(Y, dev)
+        key = (scaling if world > 1 else "weak", bool(zipf))
+        if key not in matrices:      # the legs of one run share the host matrix and its copy in HBM
+            matrices.clear()
+            if scaling == "weak":
+                # rank r holds the whole n-row workload matrix, generated from its own seeds
+                Yh = make_csr_rows(n, m, 0, n, R_NNZ, seed=MATRIX_SEED + 8 * rank, zipf=zipf, k=K)
+            else:
+                Yh = make_csr_rows(n, m, lo, hi, R_NNZ, seed=MATRIX_SEED, zipf=zipf, k=K)
+            matrices[key] = (Yh, D.DeviceCSR.from_scipy(Yh, dev))
+        Y, csr = matrices[key]
         if not packed:
             os.environ["XCOLUMNS_BCA_PACKED"] = "0"
         try:

@@ -174,3 +174,46 @@ def test_deterministic_concurrent_mode(oref, zipf):
     a = f(Y, k, seed=5, max_iters=2, tolerance=-1.0, bca_deterministic=True, bca_waves=512)
     b = f(Y, k, seed=5, max_iters=2, tolerance=-1.0, bca_deterministic=True, bca_waves=512)
     assert np.array_equal(a.indices, b.indices)
+
+
+def test_final_parity_policy(oref):
+    """bca_parity="final": wider sweeps than the default (four times), the utility after the LAST sweep within 1e-5 of
+    the sequential oracle (intermediate sweeps may sit a few 1e-5 away); "per_sweep" (default) holds every sweep."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+    from xcolumns_amd.synthetic import make_csr
+
+    n, m, k = 100_000, 30_000, 5
+    Y = make_csr(n, m, 50, seed=20240001, k=k)
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=5, tolerance=-1.0)
+    _, md = f(Y, k, seed=13, max_iters=5, tolerance=-1.0, return_meta=True, bca_diagnostics=True)
+    _, mf = f(Y, k, seed=13, max_iters=5, tolerance=-1.0, return_meta=True, bca_diagnostics=True, bca_parity="final")
+    dd = np.abs(np.asarray(md["utilities"]) - np.asarray(mo["utilities"]))
+    df = np.abs(np.asarray(mf["utilities"]) - np.asarray(mo["utilities"]))
+    print("per_sweep", md["wavefronts"], dd, "\nfinal    ", mf["wavefronts"], df)
+    assert mf["wavefronts"][0] == 4 * md["wavefronts"][0]
+    assert dd.max() < 1e-5 and df[-1] < 1e-5 and df.max() < 5e-5
+    with pytest.raises(ValueError):
+        f(Y, k, bca_parity="sometimes")
+
+
+def test_visiting_order_paths_agree():
+    """The visiting order reaches the sweeps through a worker thread, a pinned buffer and -- when numpy's generator
+    is the PCG64 this build was checked against -- the library's own walk of numpy's stream; whichever path is
+    taken, the exact mode returns the same prediction (the orders are the same)."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+    from xcolumns_amd.synthetic import make_csr
+
+    Y = make_csr(60_000, 8_000, 30, seed=4, k=5)
+    runs = []
+    for env in ({}, {"XCOLUMNS_ORDER_FAST_SHUFFLE": "0"}, {"XCOLUMNS_ORDER_PREFETCH": "0"},
+                {"XCOLUMNS_ORDER_PREFETCH": "0", "XCOLUMNS_ORDER_FAST_SHUFFLE": "0"}):
+        os.environ.update(env)
+        try:
+            P, meta = f(Y, 5, seed=21, max_iters=2, tolerance=-1.0, return_meta=True, bca_waves=1)
+        finally:
+            for key in env:
+                os.environ.pop(key)
+        runs.append((P.indices.copy(), meta["utilities"]))
+    for idx, u in runs[1:]:
+        assert np.array_equal(idx, runs[0][0]) and u == runs[0][1]

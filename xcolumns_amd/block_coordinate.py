@@ -149,6 +149,13 @@ class WavePolicy:
             # a single decision that falls the other way moves such a label's F1 by ~0.3, i.e. the utility by
             # 0.3 / m: on a 30 K-label space three of them are the whole 1e-5
             self.first_factor = _SKEWED_FIRST_SWEEP * min(1.0, float(m) / 200000.0) if skewed else 1.0
+            # ... and when that leaves fewer than 64 wavefronts the first sweep runs as the reference's sequential
+            # sweep: on 100 K x 30 K Zipf ONE tail label that is predicted by a different row is 1-2e-5 of utility,
+            # and 22 .. 250 wavefronts all measure 0.5-2e-5 in sweep 1 (six runs each, profiles/r02_c2_zipf_width.txt)
+            # -- anything but one row at a time is a coin toss against the bar there.
+            if (skewed and self.parity == "per_sweep" and not self.fixed
+                    and self.num * self.first_factor / (self.n * self.first_changed) < 64.0):
+                self.first_sequential = True
         self.budget = self.num / (float(self.n) * float(self.n))   # the same rule as a share of n (diagnostics)
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
