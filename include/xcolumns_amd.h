@@ -367,6 +367,16 @@ int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uint
                           uint32_t *js);
 int xc_host_shuffle_apply(int64_t n, const uint32_t *js, int32_t *order);
 
+/* Per-label sums of n_items (label, float32 value) pairs without a global float atomic per pair
+ * (csrc/xc_scatter.hip: counting sort into buckets of consecutive labels, then one workgroup per bucket sums in LDS).
+ * pair = 0: out[label] += value (the column sums of y_proba, numba_csr_functions.py:143-182 over all rows);
+ * pair = 1: out[2 label] += value, out[2 label + 1] += 1 - value (float32 subtraction: the from-scratch {tp, fp} of a
+ * prediction, block_coordinate.py:430-436).  Every label of [0, m) is written.  `workspace`: device memory of
+ * xc_scatter_sum_workspace_bytes(n_items, m) bytes. */
+int xc_scatter_sum_workspace_bytes(int64_t n_items, int64_t m, int64_t *bytes);
+int xc_scatter_sum_f32(int64_t n_items, const int32_t *idx, const float *val, int64_t m, int pair,
+                       double *out, void *workspace, void *stream);
+
 /* Busy labels: counts[m] <- how often each label occurs among every `stride`-th stored entry (indices[0], indices[stride],
  * ...), then list <- (label, sampled count) pairs of the labels with sampled count >= min_count, at most `cap` of
  * them, in arrival order; *n_list <- how many reached the threshold.  The engine picks its <= 63 hot labels from it. */

@@ -217,3 +217,37 @@ def test_visiting_order_paths_agree():
         runs.append((P.indices.copy(), meta["utilities"]))
     for idx, u in runs[1:]:
         assert np.array_equal(idx, runs[0][0]) and u == runs[0][1]
+
+
+@pytest.mark.parametrize("m", [1, 63, 1000, 30_000, 500_001, 2_800_000])
+def test_scatter_sum_against_index_add(m):
+    """xc_scatter_sum_f32 (bucketed counting sort + LDS sums) = the plain float64 scatter-add, for column sums
+    (pair = 0) and the {value, 1 - value} statistics of a prediction (pair = 1): every label written, duplicates summed,
+    label ids at both ends of the range, label spaces that are not a multiple of the bucket size."""
+    import ctypes
+
+    from xcolumns_amd import _device as D, _lib
+
+    dev = D.require_gpu()
+    g = torch.Generator(device=dev)
+    g.manual_seed(m)
+    n_items = 700_001
+    idx = torch.randint(0, m, (n_items,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    idx[:3] = 0
+    idx[-3:] = m - 1
+    val = torch.rand(n_items, generator=g, device=dev, dtype=torch.float32) ** 3
+    nbytes = ctypes.c_int64(0)
+    _lib.call("xc_scatter_sum_workspace_bytes", n_items, m, ctypes.byref(nbytes))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    for pair in (0, 1):
+        out = torch.full(((2 if pair else 1) * m + 1,), -7.0, dtype=torch.float64, device=dev)
+        _lib.call("xc_scatter_sum_f32", n_items, D.ptr(idx), D.ptr(val), m, pair, D.ptr(out), D.ptr(ws), D.stream())
+        if pair:
+            want = torch.zeros(2 * m, dtype=torch.float64, device=dev)
+            want.index_add_(0, idx.long() * 2, val.double())
+            want.index_add_(0, idx.long() * 2 + 1, (1.0 - val).double())
+        else:
+            want = torch.zeros(m, dtype=torch.float64, device=dev)
+            want.index_add_(0, idx.long(), val.double())
+        torch.testing.assert_close(out[:-1], want, rtol=0, atol=1e-9)
+        assert float(out[-1]) == -7.0                       # nothing written past the last label

@@ -112,6 +112,8 @@ SIGNATURES = {
     "xc_bca_set_tuning": (c_int, [c_double, c_double]),
     "xc_dense_pred_to_fixed": (c_int, [c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),
+    "xc_scatter_sum_workspace_bytes": (c_int, [c_int64, c_int64, POINTER(c_int64)]),
+    "xc_scatter_sum_f32": (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "xc_label_busy_list": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_exchange_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "xc_bca_det_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_int64)]),

@@ -362,11 +362,28 @@ class BcaCsrEngine:
         self.colsum.zero_()
         if not greedy:
             c = self.csr
-            _lib.call("xc_bca_colsum_csr", c.nnz, D.ptr(c.indices), D.ptr(c.data), c.code,
-                      D.ptr(self.colsum), D.stream())
+            if not self._scatter_sum(c.nnz, c.indices, c.data, self.colsum, pair=False):
+                _lib.call("xc_bca_colsum_csr", c.nnz, D.ptr(c.indices), D.ptr(c.data), c.code,
+                          D.ptr(self.colsum), D.stream())
             if self.comm is not None:
                 self.comm.all_reduce(self.colsum)
             self._expand_colsum()
+
+    def _scatter_sum(self, n_items: int, idx: torch.Tensor, val: torch.Tensor, out: torch.Tensor, pair: bool) -> bool:
+        """Per-label float64 sums of (label, float32 value) pairs by a bucketed counting sort + LDS sums
+        (xc_scatter_sum_f32: 2.1 -> ~0.6 ms for the 50 M entries of 1M x 500K) instead of one global float atomic per
+        pair.  False: not applicable (float64 values, tiny inputs, a label space beyond the bucket tables) -- the
+        caller takes the atomic kernel.  XCOLUMNS_BCA_SCATTER=0 disables."""
+        if (val.dtype != torch.float32 or n_items < (1 << 18) or self.csr.m > 16384 * 2048
+                or os.environ.get("XCOLUMNS_BCA_SCATTER", "1") == "0"):
+            return False
+        nbytes = ctypes.c_int64(0)
+        _lib.call("xc_scatter_sum_workspace_bytes", int(n_items), self.csr.m, ctypes.byref(nbytes))
+        ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.dev)
+        _lib.call("xc_scatter_sum_f32", int(n_items), D.ptr(idx), D.ptr(val), self.csr.m, int(pair), D.ptr(out), D.ptr(ws),
+                  D.stream())
+        ws.record_stream(torch.cuda.current_stream())
+        return True
 
     def _expand_colsum(self):
         """colsum changed: its per-entry copies (s_entry, the packed stream) are stale."""
@@ -404,9 +421,12 @@ class BcaCsrEngine:
         row has already accumulated them (xc_bca_sweep_csr `acc`); otherwise one pass
         over the prediction does.  Blocks on the result."""
         if not self._acc_filled:
-            self.acc.zero_()
-            _lib.call("xc_bca_accumulate_pred", self.csr.n * self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
-                      self.csr.code, D.ptr(self.acc), D.stream())
+            if self._scatter_sum(self.csr.n * self.k, self.pred_idx, self.pred_eta, self.acc, pair=True):
+                self.acc[2 * self.csr.m] = 0.0
+            else:
+                self.acc.zero_()
+                _lib.call("xc_bca_accumulate_pred", self.csr.n * self.k, D.ptr(self.pred_idx), D.ptr(self.pred_eta),
+                          self.csr.code, D.ptr(self.acc), D.stream())
         if self.comm is not None:
             self.comm.all_reduce(self.acc)
         self._acc_filled = False
