@@ -443,8 +443,8 @@ def worker(args):
         roof.update({
             "traffic": traffic,
             "algorithmic_bytes_per_row": b_sweep,
-            "algorithmic_bytes_note": "SURVEY 8(d) B_sweep = step pass 1644 (incl. 24r B of float64 statistic gathers) + fused "
-                                      "from-scratch recompute 424; the timed kernel gathers 8-byte float32 records instead "
+            "algorithmic_bytes_note": "SURVEY 8(d) B_sweep = 8 + 40r + 12k: step pass 4 + 32r + 8k (incl. 24r B of float64 statistic "
+                                      "gathers; 1644 at r = 50) + fused from-scratch recompute 4 + 8r + 4k (424); the timed kernel gathers 8-byte float32 records instead "
                                       "(see config.arithmetic, frac_f64_records)",
             "frac_whole_step": b_sweep * n_global * args.steps / med / 1e9 / (HBM_PEAK_GBS * world),
         })
@@ -629,6 +629,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank holds the workload's n rows; strong: the n rows are split over the ranks")
     ap.add_argument("--zipf", action="store_true", help="Zipf(1) label popularity instead of uniform")
+    ap.add_argument("--entries", type=int, default=50,
+                    help="stored entries per row: 50 (SURVEY 8d primary) or 100 (the reference's *_100_* prediction files)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts walking the order (0 = product default)")
     ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K-sweep timed region (median reported)")
     ap.add_argument("--exchanges", type=int, default=0, help="N > 1: exchanges of the ranks' changes per sweep (0 = product default)")
@@ -642,6 +644,10 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.repeats < 1:
         raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --repeats >= 1")
+    global R_NNZ
+    R_NNZ = int(args.entries)
+    if not (K <= R_NNZ <= 1024):
+        raise SystemExit("--entries must lie in 5..1024")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_children(args.gpus))
     worker(args)

@@ -78,7 +78,7 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 # 3.3e-5 (Zipf) standard deviation in sweep 1 when only its visiting order (`seed`) changes.
 #
 # bca_parity = "per_sweep" (default): EVERY sweep within north_star's 1e-5 of the sequential reference --
-#     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * n / (2 * rows changed in sweep j-1)
+#     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * min(1, n k / 16 m)^2.5 * min(1, m / 30K)^0.5 * n / (2 * rows changed in sweep j-1)
 #     (half of the rows assumed before sweep 1), an eighth of it (less when m < 200 K) for the first sweep when the label
 #     popularity is skewed (hot labels present); converged sweeps use the whole GPU.
 # bca_parity = "final": four times wider -- the utility after the LAST sweep is what is held to 1e-5
@@ -134,14 +134,15 @@ class WavePolicy:
             # labels that hold about one predicted row each (n * k / m ~ 1: 150 K rows x 670 K labels) react to a
             # single row in flight with their whole statistic, and the differences no longer heal -- the
             # landscape is full of nearly equivalent optima (C3: 1e-5 at 0.4 % of the rows in flight, in every
-            # sweep): the width shrinks with the square of the predicted rows per label below 16
+            # sweep; 131 wavefronts: 0.3e-6 .. 1.3e-5 from run to run): the width shrinks with the 2.5th power of the
+            # predicted rows per label below 16 (C3: 35 wavefronts)
             per_label = float(self.n) * self.world * max(1, int(k)) / float(m)
             # and the bar is absolute: one label's F1 weighs 1 / m in the utility, so on a small label space a
             # handful of decisions that fall the other way are already 1e-5 (20 K x 5 K: 1.0-1.7e-5 at 0.064 m
             # rows in flight, 4e-6 at half of that)
             small_m = min(1.0, float(m) / 30000.0) ** 0.5
             width = (_BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
-                     * min(1.0, per_label / 16.0) ** 2 * small_m)
+                     * min(1.0, per_label / 16.0) ** 2.5 * small_m)
             if self.parity == "final":
                 width *= _FINAL_PARITY_FACTOR
             self.num = width * self.n / 2.0
@@ -258,10 +259,10 @@ class BcaCsrEngine:
         self.hot_slot = self.hot_labels = None
         self.skewed = False      # a label stored in >= n/32 rows: the first sweep from top-k changes nearly every row
         if csr.nnz > 0:
-            # label frequencies from a strided sample of the stored entries (at most ~4 M of them): a label
+            # label frequencies from a strided sample of the stored entries (at most ~512 K of them: a label stored in n / 32 rows is hit ~300 times): a label
             # stored in n / 32 rows shows up thousands of times in it, and the hot set only steers how the
             # kernel batches its atomics -- not worth a full histogram of the matrix (2.1 ms at 1M x 500K)
-            stride = max(1, csr.nnz // (1 << 22))
+            stride = max(1, csr.nnz // (1 << 19))
             # "hot" presumes a record that sums so many rows that a few rows' delay cannot move a gain: at
             # least 4096 stored entries (a label stored in 500 of 6000 rows is busy, but its tp is ~10)
             busy_min, hot_min = max(64, csr.n // 32), max(4096, csr.n // 32)

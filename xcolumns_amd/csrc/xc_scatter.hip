@@ -63,14 +63,33 @@ __global__ __launch_bounds__(XC_BLOCK) void scatter_scan_chunks_kernel(ScatterPl
     }
 }
 
-__global__ void scatter_scan_buckets_kernel(int n_buckets, const int32_t *totals, int64_t *base) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int64_t run = 0;
-    for (int b = 0; b < n_buckets; ++b) {
-        base[b] = run;
-        run += totals[b];
+// exclusive scan of the bucket totals (one workgroup; the totals are staged in LDS so the serial part runs on LDS latency)
+__global__ __launch_bounds__(XC_BLOCK) void scatter_scan_buckets_kernel(int n_buckets, const int32_t *totals, int64_t *base) {
+    extern __shared__ int s_tot[];
+    for (int b = threadIdx.x; b < n_buckets; b += XC_BLOCK) s_tot[b] = totals[b];
+    __syncthreads();
+    __shared__ long long s_part[XC_BLOCK];
+    const int per = (n_buckets + XC_BLOCK - 1) / XC_BLOCK;
+    const int b0 = threadIdx.x * per, b1 = b0 + per < n_buckets ? b0 + per : n_buckets;
+    long long sum = 0;
+    for (int b = b0; b < b1; ++b) sum += s_tot[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < XC_BLOCK; ++i) {
+            const long long v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+        base[n_buckets] = run;
     }
-    base[n_buckets] = run;
+    __syncthreads();
+    long long run = s_part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+        base[b] = run;
+        run += s_tot[b];
+    }
 }
 
 struct __attribute__((aligned(8))) sc_item_t {
@@ -130,7 +149,8 @@ static ScatterPlan make_plan(int64_t n_items, int64_t m, int pair) {
     while (((m + (1ll << shift) - 1) >> shift) > 512 && (1 << shift) < XC_SC_BUCKET_LABELS_MAX) ++shift;
     S.shift = shift;
     S.n_buckets = (int)((m + (1ll << shift) - 1) >> shift);
-    int64_t chunks = (n_items + 16383) / 16384;
+    // many more chunks than CUs (an even load; 256 CUs take a 305-chunk grid in two uneven rounds), at least 2048 pairs each
+    int64_t chunks = (n_items + 2047) / 2048;
     if (chunks > XC_SC_CHUNKS_MAX) chunks = XC_SC_CHUNKS_MAX;
     if (chunks < 1) chunks = 1;
     S.n_chunks = (int)chunks;
@@ -173,7 +193,7 @@ int xc_scatter_sum_f32(int64_t n_items, const int32_t *idx, const float *val, in
     const size_t hist_bytes = (size_t)S.n_buckets * 4;
     hipLaunchKernelGGL(xc::scatter_count_kernel, dim3(S.n_chunks), dim3(XC_BLOCK), hist_bytes, st, S, idx, counts);
     hipLaunchKernelGGL(xc::scatter_scan_chunks_kernel, dim3(S.n_buckets), dim3(XC_BLOCK), 0, st, S, counts, totals);
-    hipLaunchKernelGGL(xc::scatter_scan_buckets_kernel, dim3(1), dim3(64), 0, st, S.n_buckets, totals, base);
+    hipLaunchKernelGGL(xc::scatter_scan_buckets_kernel, dim3(1), dim3(XC_BLOCK), hist_bytes, st, S.n_buckets, totals, base);
     hipLaunchKernelGGL(xc::scatter_move_kernel, dim3(S.n_chunks), dim3(XC_BLOCK), hist_bytes, st, S, idx, val, counts, base, items);
     const size_t acc_bytes = (size_t)(1 << S.shift) * (pair ? 16 : 8);
     hipLaunchKernelGGL(xc::scatter_reduce_kernel, dim3(S.n_buckets), dim3(XC_BLOCK), acc_bytes, st, S, base, items, out);
