@@ -36,6 +36,13 @@ static inline uint64_t pcg64_next64(Pcg64 &g) {
     return (x >> rot) | (x << ((64 - rot) & 63));
 }
 
+static inline uint64_t pcg64_output(u128 state) { // XSL-RR of a state that has already been stepped
+    const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
+    const unsigned rot = (unsigned)(hi >> 58);
+    const uint64_t x = hi ^ lo;
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+
 static inline uint32_t pcg64_next32(Pcg64 &g) {
     if (g.has_uint32) {
         g.has_uint32 = 0;
@@ -141,6 +148,16 @@ int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uint
     g.uinteger = *uinteger_io;
     int64_t i = n - 1;
     uint32_t *out = js;
+    u128 jump_a[4], jump_c[4];
+    {
+        const u128 mult = ((u128)2549297995355413924ULL << 64) | (u128)4865540595714422341ULL;
+        jump_a[0] = mult;
+        jump_c[0] = g.inc;
+        for (int q = 1; q < 4; ++q) {
+            jump_a[q] = jump_a[q - 1] * mult;
+            jump_c[q] = jump_c[q - 1] * mult + g.inc;
+        }
+    }
     while (i >= 1) {
         uint64_t mask = (uint64_t)i;
         mask |= mask >> 1;
@@ -159,6 +176,34 @@ int xc_host_shuffle_draws(uint64_t *state_io, int *has_uint32_io, uint32_t *uint
             const uint32_t v = g.uinteger & m32;
             out[got] = v;
             got += (v <= (uint32_t)(i - got)) ? 1 : 0;
+        }
+        // Eight candidates (four 64-bit outputs) at a time.  The four generator steps are computed from ONE state with
+        // jump-ahead constants (state_{n+k} = A_k state_n + C_k), so they do not wait for each other; and the eight
+        // bounds i - got differ by at most 7, so a candidate <= i - got - 8 is accepted and one > i - got is rejected
+        // whatever the others do -- unless a candidate falls into that 8-wide band (rare: the range is ~i wide) the
+        // accept flags are independent of `got` and only the one-cycle `got += flag` chain is left.
+        while (got + 8 <= cnt) {
+            const u128 s0 = g.state;
+            const u128 s1 = s0 * jump_a[0] + jump_c[0], s2 = s0 * jump_a[1] + jump_c[1];
+            const u128 s3 = s0 * jump_a[2] + jump_c[2], s4 = s0 * jump_a[3] + jump_c[3];
+            g.state = s4;
+            const uint64_t w0 = pcg64_output(s1), w1 = pcg64_output(s2), w2 = pcg64_output(s3), w3 = pcg64_output(s4);
+            const uint32_t c[8] = {(uint32_t)w0 & m32, (uint32_t)(w0 >> 32) & m32, (uint32_t)w1 & m32, (uint32_t)(w1 >> 32) & m32,
+                                   (uint32_t)w2 & m32, (uint32_t)(w2 >> 32) & m32, (uint32_t)w3 & m32, (uint32_t)(w3 >> 32) & m32};
+            const uint32_t hi_b = (uint32_t)(i - got), lo_b = hi_b - 8u; // i - got >= low + 7 >= 8 here
+            unsigned band = 0;
+            for (int q = 0; q < 8; ++q) band |= (unsigned)((c[q] > lo_b) & (c[q] <= hi_b));
+            if (!band) {
+                for (int q = 0; q < 8; ++q) {
+                    out[got] = c[q];
+                    got += (c[q] <= lo_b) ? 1 : 0;
+                }
+            } else {
+                for (int q = 0; q < 8; ++q) {
+                    out[got] = c[q];
+                    got += (c[q] <= (uint32_t)(i - got)) ? 1 : 0;
+                }
+            }
         }
         while (got < cnt) {
             const uint64_t w = pcg64_next64(g);

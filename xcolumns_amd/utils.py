@@ -215,7 +215,13 @@ class Pcg64Shuffler:
         import ctypes
 
         from . import _lib
-        js = np.empty(max(0, self.n - 1), dtype=np.uint32)
+        # a small ring of buffers: fresh pages cost more to touch than the draws to make (1.7 of 4 ms at 1 M rows);
+        # the consumer holds at most two queued + one being applied while the next is filled
+        if getattr(self, "_js_pool", None) is None:
+            self._js_pool = [np.zeros(max(0, self.n - 1), dtype=np.uint32) for _ in range(5)]
+            self._js_next = 0
+        js = self._js_pool[self._js_next]
+        self._js_next = (self._js_next + 1) % len(self._js_pool)
         st = self.rng.bit_generator.state
         s_, inc = int(st["state"]["state"]), int(st["state"]["inc"])
         mask = (1 << 64) - 1
