@@ -12,6 +12,7 @@
  *
  * Included by xc_oracle.c once per value type (T, SFX), after xc_oracle_impl.h.
  */
+#include <omp.h>
 #define XC_PASTE2(a, b) a##b
 #define XC_PASTE(a, b) XC_PASTE2(a, b)
 #define FN(name) XC_PASTE(name, SFX)
@@ -59,12 +60,15 @@ void FN(oracle_confusion_csr_mt)(int64_t n, int64_t m, const int32_t *t_indptr, 
         if (sz > cap) cap = sz;
     }
     for (int64_t j = 0; j < m; ++j) tp[j] = fp[j] = fn[j] = 0.0;
+    if (n_threads < 1) n_threads = 1;
+    /* one private {tp | fp | fn} block per thread, summed over the threads label-parallel at the end */
+    double *all = (double *)calloc((size_t)n_threads * 3 * (size_t)m, sizeof(double));
 #pragma omp parallel num_threads(n_threads)
     {
         T *od = (T *)malloc(sizeof(T) * (size_t)cap);
         int32_t *oi = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
         double *tmp = (double *)malloc(sizeof(double) * (size_t)cap);
-        double *mine = (double *)calloc((size_t)(3 * m), sizeof(double));
+        double *mine = all + (size_t)omp_get_thread_num() * 3 * (size_t)m;
         for (int pass = 0; pass < 3; ++pass) {
             double *dst = mine + (int64_t)pass * m;
 #pragma omp for schedule(static) nowait
@@ -82,17 +86,26 @@ void FN(oracle_confusion_csr_mt)(int64_t n, int64_t m, const int32_t *t_indptr, 
                 FN(oracle_scatter)(dst, oi, od, c, 1.0, tmp);
             }
         }
-#pragma omp critical
-        for (int64_t j = 0; j < m; ++j) {
-            tp[j] += mine[j];
-            fp[j] += mine[m + j];
-            fn[j] += mine[2 * m + j];
-        }
         free(od);
         free(oi);
         free(tmp);
-        free(mine);
+#pragma omp barrier
+        const int nt = omp_get_num_threads();
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < m; ++j) {
+            double a = 0.0, b = 0.0, c = 0.0;
+            for (int t = 0; t < nt; ++t) {
+                const double *blk = all + (size_t)t * 3 * (size_t)m;
+                a += blk[j];
+                b += blk[m + j];
+                c += blk[2 * m + j];
+            }
+            tp[j] = a;
+            fp[j] = b;
+            fn[j] = c;
+        }
     }
+    free(all);
 }
 
 #undef FN

@@ -95,7 +95,7 @@ def test_order_worker_delivers_the_reference_stream():
     n = 120_000
     dev = D.require_gpu()
     src = _OrderSource(n, 13, True, "numpy", dev)
-    assert src._thread is not None
+    assert src._threaded
     rng = np.random.default_rng(13)
     ref = np.arange(n)
     try:
@@ -106,7 +106,7 @@ def test_order_worker_delivers_the_reference_stream():
             assert got.dtype == torch.int32 and got.is_cuda and np.array_equal(got.cpu().numpy(), ref.astype(np.int32))
     finally:
         src.close()
-    assert src._thread is None
+    assert not src._threaded
 
 
 def test_rccl_all_reduce_through_torchcomm():

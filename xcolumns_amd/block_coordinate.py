@@ -664,15 +664,67 @@ _ORDER_PREFETCH_ROWS = 50_000   # below this a sweep's order is cheaper to make 
 _ORDER_PREFETCH_DEPTH = 3        # orders generated ahead of the sweep that consumes them
 
 
+class _OrderWorkers:
+    """Two persistent host threads that prepare visiting orders ahead of the sweeps: one generates the swap partners
+    (the sequential PCG64 arithmetic), the other applies the swaps and copies the order to the GPU on a side stream.
+    Persistent because a thread's first HIP calls (device context, stream, pinned allocation) cost tens of
+    milliseconds -- threads started per call made the call 2-4x slower and erratic (measured: 40-175 ms against 27-41
+    ms in line at 1 M rows; 23 ms with the persistent pair).  One run at a time uses them; a concurrent caller simply
+    generates its orders in line."""
+
+    _lock = None
+    _busy = False
+    _queues = None
+    _resources = {}     # copy thread only: (device index) -> side stream; (device index, n) -> pinned slots
+
+    @classmethod
+    def acquire(cls) -> bool:
+        import queue
+        import threading
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        with cls._lock:
+            if cls._busy:
+                return False
+            if cls._queues is None:
+                cls._queues = (queue.Queue(), queue.Queue())
+                for q, name in zip(cls._queues, ("xcolumns-order-draws", "xcolumns-order-copy")):
+                    threading.Thread(target=cls._serve, args=(q,), name=name, daemon=True).start()
+            cls._busy = True
+            return True
+
+    @classmethod
+    def release(cls) -> None:
+        with cls._lock:
+            cls._busy = False
+
+    @staticmethod
+    def _serve(q):
+        while True:
+            job, done = q.get()
+            try:
+                job()
+            finally:
+                done.set()
+
+    @classmethod
+    def submit(cls, which: int, job):
+        import threading
+        done = threading.Event()
+        cls._queues[which].put((job, done))
+        return done
+
+
 class _OrderSource:
     """Visiting order per sweep (block_coordinate.py:413-419): the reference's stream --
     ``np.random.default_rng(seed)``, ONE array shuffled cumulatively, once per iteration.
 
-    The shuffle is sequential host work (7.6 ms for 1 M rows, 12x the sweep it feeds), so for large
-    matrices it runs on a worker thread, up to _ORDER_PREFETCH_DEPTH sweeps ahead (numpy releases the GIL
-    inside ``Generator.shuffle``): the order of sweep j + 1 is shuffled, narrowed to int32 into a pinned
-    buffer and copied to the GPU on a side stream while sweep j runs; ``next()`` makes the compute stream
-    wait for that copy only.  Same stream, same orders -- the loop just stops waiting for them."""
+    The shuffle is sequential host work (numpy: 8 ms for 1 M rows, 12x the sweep it feeds).  For large matrices it is
+    (a) done by the library's own walk of numpy's stream (utils.Pcg64Shuffler: same permutation, 2.3 ms of draws +
+    0.8 ms of swaps) and (b) taken off the critical path: the draws of sweep j + 2 and the swaps + upload of sweep
+    j + 1 run on two persistent worker threads (:class:`_OrderWorkers`; the C routines release the GIL) while sweep j
+    runs; ``next()`` makes the compute stream wait for the copy only.  Same stream, same orders -- the loop just
+    stops waiting for them."""
 
     def __init__(self, n: int, seed, shuffle: bool, backend: str, dev, prefetch: Optional[bool] = None):
         self.n, self.shuffle, self.backend, self.dev = n, shuffle, backend, dev
@@ -681,7 +733,7 @@ class _OrderSource:
         self.rng = np.random.default_rng(seed)       # :413
         self.order = np.arange(n)                     # :414, shuffled cumulatively
         self.gen = None
-        self._thread = None
+        self._threaded = False
         # the same walk and stream as rng.shuffle, 2-3x faster (utils.Pcg64Shuffler); numpy's own when it is not
         # the PCG64 generator this build was checked against, or for small orders
         self._fast = None
@@ -695,41 +747,61 @@ class _OrderSource:
             self.gen.manual_seed(int(seed) if seed is not None else int(self.rng.integers(2 ** 31)))
         if prefetch is None:
             prefetch = os.environ.get("XCOLUMNS_ORDER_PREFETCH", "1") != "0"
-        if backend == "numpy" and shuffle and prefetch and n >= _ORDER_PREFETCH_ROWS:
+        if backend == "numpy" and shuffle and prefetch and n >= _ORDER_PREFETCH_ROWS and _OrderWorkers.acquire():
             import queue
             import threading
+            self._threaded = True
             self._q = queue.Queue(maxsize=_ORDER_PREFETCH_DEPTH - 1)
+            self._jq = queue.Queue(maxsize=2)
             self._stop = threading.Event()
             self._error = None
-            self._draw_thread = None
+            self._jobs = []
             if self._fast is not None:
-                # two stages: the draws of sweep j + 1 (sequential PCG64 arithmetic, independent of the array) are
-                # generated while the swaps of sweep j are applied (memory-bound) -- both release the GIL in ctypes
-                self._jq = queue.Queue(maxsize=2)
-                self._draw_thread = threading.Thread(target=self._produce_draws, name="xcolumns-order-draws", daemon=True)
-                self._draw_thread.start()
-            self._thread = threading.Thread(target=self._produce, name="xcolumns-order", daemon=True)
-            self._thread.start()
+                self._jobs.append(_OrderWorkers.submit(0, self._produce_draws))
+            self._jobs.append(_OrderWorkers.submit(1, self._produce))
+
+    def _put(self, q, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                q.put(item, timeout=0.02)
+                return True
+            except Exception:
+                continue
+        return False
+
+    def _get(self, q):
+        while not self._stop.is_set():
+            if self._error is not None:
+                return None
+            try:
+                return q.get(timeout=0.02)
+            except Exception:
+                continue
+        return None
 
     def _produce_draws(self):
         try:
             while not self._stop.is_set():
-                js = self._fast.draws()
-                while not self._stop.is_set():
-                    try:
-                        self._jq.put(js, timeout=0.05)
-                        break
-                    except Exception:
-                        continue
+                if not self._put(self._jq, self._fast.draws()):
+                    break
         except BaseException as e:
             self._error = e
 
     def _produce(self):
         try:
             torch.cuda.set_device(self.dev)
-            side = torch.cuda.Stream(device=self.dev)
+            res = _OrderWorkers._resources
+            di = torch.device(self.dev).index or 0
+            side = res.get(di)
+            if side is None:
+                side = res[di] = torch.cuda.Stream(device=self.dev)
             slots = _ORDER_PREFETCH_DEPTH + 1      # one being filled, DEPTH - 1 queued, one in the consumer's hands
-            pinned = [torch.empty(self.n, dtype=torch.int32).pin_memory() for _ in range(slots)]
+            key = (di, self.n)
+            if key not in res:
+                for old in [k for k in res if isinstance(k, tuple)]:
+                    del res[old]                  # one size at a time: the buffers of the previous matrix go
+                res[key] = [torch.empty(self.n, dtype=torch.int32).pin_memory() for _ in range(slots)]
+            pinned = res[key]
             done = [None] * slots
             i = 0
             while not self._stop.is_set():
@@ -737,14 +809,7 @@ class _OrderSource:
                 if done[slot] is not None:
                     done[slot].synchronize()          # its previous copy has left the pinned buffer
                 if self._fast is not None:
-                    js = None
-                    while js is None and not self._stop.is_set():
-                        if self._error is not None:
-                            raise self._error
-                        try:
-                            js = self._jq.get(timeout=0.05)
-                        except Exception:
-                            js = None
+                    js = self._get(self._jq)
                     if js is None:
                         break
                     np.copyto(pinned[slot].numpy(), self._fast.apply(js))   # :418-419, the swaps of the int32 walk
@@ -757,25 +822,20 @@ class _OrderSource:
                     ev.record(side)
                 done[slot] = ev
                 i += 1
-                while not self._stop.is_set():
-                    try:
-                        self._q.put((d, ev), timeout=0.05)
-                        break
-                    except Exception:
-                        continue
+                if not self._put(self._q, (d, ev)):
+                    break
+            for ev in done:                           # the pinned buffers outlive this run: let their copies finish
+                if ev is not None:
+                    ev.synchronize()
         except BaseException as e:                    # surfaced by next()
             self._error = e
-            try:
-                self._q.put_nowait(None)
-            except Exception:
-                pass
 
     def next(self) -> Optional[torch.Tensor]:
         if not self.shuffle:
             return None
-        if self._thread is not None:
-            item = self._q.get()
-            if item is None or self._error is not None:
+        if self._threaded:
+            item = self._get(self._q)
+            if item is None:
                 raise RuntimeError(f"visiting-order worker failed: {self._error!r}")
             d, ev = item
             torch.cuda.current_stream().wait_event(ev)
@@ -789,24 +849,13 @@ class _OrderSource:
         return torch.randperm(self.n, generator=self.gen, device=self.dev, dtype=torch.int32)
 
     def close(self):
-        """Stop the worker (orders generated ahead of an early stop are dropped)."""
-        if self._thread is not None:
+        """Stop the workers' jobs (orders generated ahead of an early stop are dropped) and hand the workers back."""
+        if self._threaded:
             self._stop.set()
-            try:
-                while True:
-                    self._q.get_nowait()
-            except Exception:
-                pass
-            self._thread.join(timeout=5.0)
-            self._thread = None
-            if getattr(self, "_draw_thread", None) is not None:
-                try:
-                    while True:
-                        self._jq.get_nowait()
-                except Exception:
-                    pass
-                self._draw_thread.join(timeout=5.0)
-                self._draw_thread = None
+            for done in self._jobs:
+                done.wait(timeout=10.0)
+            self._threaded = False
+            _OrderWorkers.release()
 
     def __del__(self):
         try:
