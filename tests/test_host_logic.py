@@ -277,9 +277,9 @@ def test_wave_policy_rules():
         z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
         assert z.first_sequential and z.next(None) == 1 and z.next(100_000) == 600            # < 64 wavefronts: sequential
         zf = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True, parity="final")
-        assert not zf.first_sequential and zf.next(None) == int(4800 * 0.125 * 30_000 / 200_000) == 90
+        assert not zf.first_sequential and zf.next(None) == int(4800 * 0.077 * 30_000 / 200_000) == 55
         zl = bc.WavePolicy(1_000_000, m=500_000, row_nnz=50, k=5, skewed=True)
-        assert not zl.first_sequential and zl.next(None) == int(0.04 * 500_000 * (10 / 16) ** 2.5 * 0.125) == 772                                   # only the FIRST sweep is narrowed
+        assert not zl.first_sequential and zl.next(None) == int(0.04 * 500_000 * (10 / 12) ** 2.5 * 0.077) == 976                                   # only the FIRST sweep is narrowed
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 4800
         num, world, min_w, max_w, fixed = p.device_params()
         assert int(num / 50_000) == p.next(50_000) and (world, fixed, max_w) == (1, 0, 8192)

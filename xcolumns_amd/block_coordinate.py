@@ -78,15 +78,15 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 # 3.3e-5 (Zipf) standard deviation in sweep 1 when only its visiting order (`seed`) changes.
 #
 # bca_parity = "per_sweep" (default): EVERY sweep within north_star's 1e-5 of the sequential reference --
-#     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * min(1, n k / 16 m)^2.5 * min(1, m / 30K)^0.5 * n / (2 * rows changed in sweep j-1)
-#     (half of the rows assumed before sweep 1), an eighth of it (less when m < 200 K) for the first sweep when the label
+#     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * min(1, n k / 12 m)^2.5 * min(1, m / 30K)^0.5 * n / (2 * rows changed in sweep j-1)
+#     (half of the rows assumed before sweep 1), a thirteenth of it (less when m < 200 K) for the first sweep when the label
 #     popularity is skewed (hot labels present); converged sweeps use the whole GPU.
 # bca_parity = "final": four times wider -- the utility after the LAST sweep is what is held to 1e-5
 #     (intermediate sweeps of a top-k start stay within ~5e-5), for callers that only use the result.
 # A changing row moves more labels the larger k is and the trajectories then settle in different, nearly
 # equivalent optima (k = 64, n = 6000, m = 900: 1.6e-4 in sweep 1 at the k = 5 width, 1.3e-5 with (5 / k)^1.5), hence (5 / k)^2.
 _BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.04"))
-_SKEWED_FIRST_SWEEP = 0.125
+_SKEWED_FIRST_SWEEP = 0.077
 _FINAL_PARITY_FACTOR = 4.0
 _STALE_BUDGET = float(os.environ["XCOLUMNS_BCA_STALE_BUDGET"]) if "XCOLUMNS_BCA_STALE_BUDGET" in os.environ else None
 _MIN_WAVES = 1
@@ -135,14 +135,14 @@ class WavePolicy:
             # single row in flight with their whole statistic, and the differences no longer heal -- the
             # landscape is full of nearly equivalent optima (C3: 1e-5 at 0.4 % of the rows in flight, in every
             # sweep; 131 wavefronts: 0.3e-6 .. 1.3e-5 from run to run): the width shrinks with the 2.5th power of the
-            # predicted rows per label below 16 (C3: 35 wavefronts)
+            # predicted rows per label below 12 (C3: 72 wavefronts; the north-star shape, 10 rows per label, keeps the whole GPU)
             per_label = float(self.n) * self.world * max(1, int(k)) / float(m)
             # and the bar is absolute: one label's F1 weighs 1 / m in the utility, so on a small label space a
             # handful of decisions that fall the other way are already 1e-5 (20 K x 5 K: 1.0-1.7e-5 at 0.064 m
             # rows in flight, 4e-6 at half of that)
             small_m = min(1.0, float(m) / 30000.0) ** 0.5
             width = (_BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
-                     * min(1.0, per_label / 16.0) ** 2.5 * small_m)
+                     * min(1.0, per_label / 12.0) ** 2.5 * small_m)
             if self.parity == "final":
                 width *= _FINAL_PARITY_FACTOR
             self.num = width * self.n / 2.0
