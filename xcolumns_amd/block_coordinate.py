@@ -146,6 +146,11 @@ class WavePolicy:
             if self.parity == "final":
                 width *= _FINAL_PARITY_FACTOR
             self.num = width * self.n / 2.0
+            # ... and since the differences do not heal there, converging sweeps may not widen freely either: at most
+            # twice the first sweep's width while a label holds fewer than four predicted rows (C3, third sweep at
+            # 1.5x the first width: 9.2e-6; constant width 146: 8.6e-6, 3.8e-6, 6.1e-6, 4.1e-6, 3.1e-6)
+            if per_label < 4.0:
+                self.width_cap = max(1, int(2.0 * width))
             # skewed popularity: every row changes in sweep 1, mostly into tail labels that hold one or two rows --
             # a single decision that falls the other way moves such a label's F1 by ~0.3, i.e. the utility by
             # 0.3 / m: on a 30 K-label space three of them are the whole 1e-5
@@ -160,6 +165,8 @@ class WavePolicy:
         self.budget = self.num / (float(self.n) * float(self.n))   # the same rule as a share of n (diagnostics)
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
+        if getattr(self, "width_cap", None) is not None:
+            self.cap = min(self.cap, self.width_cap)
 
     def next(self, changed_prev: Optional[int] = None, greedy: bool = False) -> int:
         """`greedy`: the first sweep of init_y_pred="greedy" -- every row is added to statistics that
