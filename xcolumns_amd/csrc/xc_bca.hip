@@ -380,6 +380,9 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         bool row_changed = false;
         const bool commit_mode = !EXACT && !greedy && P.validate == 2;
         const int kk = r < k ? r : k;
+        float2_t pf[CH]; // next row's records, loaded only to warm L2 (narrow sweeps; see below)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) pf[c] = float2_t{0.0f, 0.0f};
         for (int attempt = 0;; ++attempt) {
         // ---- gains (block_coordinate.py:248-282) ----
         unsigned long long key[CH];
@@ -443,8 +446,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // results nobody uses -- the real gather still happens after this row's commit, coherently (sc1), and finds
         // the lines there unless an atomic dropped them meanwhile.  Wide sweeps are bound by the L2 request rate and
         // skip this.
-        float2_t pf[CH];
-        if (SHADOW && prefetch_next) {
+        if (SHADOW && prefetch_next && attempt == 0) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const unsigned off = (hot_on && nxt.hot[c] != 0) ? 0xFFFFFFF0u : (unsigned)nxt.idx[c] * 8u;
