@@ -150,6 +150,8 @@ class WavePolicy:
             # twice the first sweep's width while a label holds fewer than four predicted rows (C3, third sweep at
             # 1.5x the first width: 9.2e-6; constant width 146: 8.6e-6, 3.8e-6, 6.1e-6, 4.1e-6, 3.1e-6)
             if per_label < 4.0:
+                width *= 0.5     # three runs at 71 / 39 / 110 wavefronts ended sweep 3 at 2.9e-6, 8.7e-6, 9.0e-6: too close
+                self.num = width * self.n / 2.0
                 self.width_cap = max(1, int(2.0 * width))
             # skewed popularity: every row changes in sweep 1, mostly into tail labels that hold one or two rows --
             # a single decision that falls the other way moves such a label's F1 by ~0.3, i.e. the utility by
