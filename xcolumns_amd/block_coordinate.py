@@ -590,6 +590,10 @@ class BcaCsrEngine:
             # of 1/2 .. 1 blocking segments (blocking: 0 .. 1): about the same staleness, no waiting.
             overlap = (os.environ.get("XCOLUMNS_BCA_EXCHANGE_OVERLAP", "1") != "0" and hasattr(self.comm, "all_reduce_async"))
             parts = min(2 * segments, 16, max(1, n)) if overlap else segments
+            # a part is its own launch (ramp-up and drain ~10 us): a small shard is not cut finer than 16 K rows per
+            # part, except for the parts the iteration needs to contract (distributed.min_exchanges)
+            from .distributed import min_exchanges
+            parts = max(min(parts, max(1, n // 16384)), min(segments, min_exchanges(self.comm.world)))
             self.exchanges_used[-1] = parts
             bounds = [n * s // parts for s in range(parts + 1)]
             pending = None

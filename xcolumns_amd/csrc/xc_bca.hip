@@ -119,7 +119,6 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 #define XC_PACK_COL_MASK 0x01ffffffu
 #define XC_PACK_HOT_SHIFT 25
 #define XC_PACK_HOT_MASK 63u
-#define XC_PREFETCH_MAX_WAVES 2048 /* sweeps this narrow warm L2 with the next row's records (latency-bound regime) */
 #define XC_HOT_FLUSH_ROWS 8      /* a wave publishes its hot-label deltas every this many rows */
 
 template <typename T, int CH>
@@ -205,7 +204,6 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     const bool greedy = P.greedy != 0;
     const bool skip_tn = P.skip_tn != 0;
     const int64_t W = n_walk;
-    const bool prefetch_next = n_walk <= XC_PREFETCH_MAX_WAVES;
     const int64_t last = P.n_order - 1;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.tpfp, 0, P.tpfp_bytes, XC_RSRC_WORD3);
     // float32 shadow of the records: only the concurrent (non-exact), non-greedy sweep reads it
@@ -380,9 +378,6 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         bool row_changed = false;
         const bool commit_mode = !EXACT && !greedy && P.validate == 2;
         const int kk = r < k ? r : k;
-        float2_t pf[CH]; // next row's records, loaded only to warm L2 (narrow sweeps; see below)
-#pragma unroll
-        for (int c = 0; c < CH; ++c) pf[c] = float2_t{0.0f, 0.0f};
         for (int attempt = 0;; ++attempt) {
         // ---- gains (block_coordinate.py:248-282) ----
         unsigned long long key[CH];
@@ -440,19 +435,6 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         }
 
         XC_STAMP(2); // wait for the gathers + gains
-        // A narrow sweep (few wavefronts under the parity bar) is latency-bound, and a third of its gathers miss the
-        // XCD's L2 (the record table of a large label space does not fit, and a few hundred waves leave it cold):
-        // while this row is selected and committed, the NEXT row's records are pulled into L2 by plain loads whose
-        // results nobody uses -- the real gather still happens after this row's commit, coherently (sc1), and finds
-        // the lines there unless an atomic dropped them meanwhile.  Wide sweeps are bound by the L2 request rate and
-        // skip this.
-        if (SHADOW && prefetch_next && attempt == 0) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const unsigned off = (hot_on && nxt.hot[c] != 0) ? 0xFFFFFFF0u : (unsigned)nxt.idx[c] * 8u;
-                pf[c] = __builtin_bit_cast(float2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc32, (int)off, 0, 0));
-            }
-        }
         // ---- top-k (numba_set_gains_csr -> numba_argtopk_csr,
         // numba_csr_functions.py:455-466, :514-524).
         // Fast path: start from the current prediction and swap its worst member
@@ -728,10 +710,6 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // gathers statistics for its next row
         if (P.n_waves == 1) __builtin_amdgcn_s_waitcnt(0);
 
-        if (SHADOW && prefetch_next) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) asm volatile("" ::"v"(pf[c].x), "v"(pf[c].y)); // keeps the loads; waited for here
-        }
         XC_STAMP(4); // stores + atomics
         // ---- rotate the pipeline ----
         cur = nxt;
