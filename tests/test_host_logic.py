@@ -270,22 +270,22 @@ def test_wave_policy_rules():
     bc._lib.device_info = lambda: monkey_info
     try:
         p = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5)
-        assert p.next(None) == int(0.04 * 30_000) == 1200
-        assert p.next(50_000) == 1200 and p.next(25_000) == 2400 and p.next(10) == 8192      # cap = resident waves
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(None) == 600             # longer rows: more candidates per row
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(None) == 300             # (5 / k)^2
+        assert p.next(None) == int(0.05 * 30_000) == 1500
+        assert p.next(50_000) == 1500 and p.next(25_000) == 3000 and p.next(10) == 8192      # cap = resident waves
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(None) == 750             # longer rows: more candidates per row
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(None) == 375             # (5 / k)^2
         z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
-        assert z.first_sequential and z.next(None) == 1 and z.next(100_000) == 600            # < 64 wavefronts: sequential
+        assert z.first_sequential and z.next(None) == 1 and z.next(100_000) == 750            # < 64 wavefronts: sequential
         zf = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True, parity="final")
-        assert not zf.first_sequential and zf.next(None) == int(4800 * 0.077 * 30_000 / 200_000) == 55
+        assert not zf.first_sequential and zf.next(None) == int(6000 * 0.0616 * 30_000 / 200_000) == 55
         zl = bc.WavePolicy(1_000_000, m=500_000, row_nnz=50, k=5, skewed=True)
-        assert not zl.first_sequential and zl.next(None) == int(0.04 * 500_000 * (10 / 12) ** 2.5 * 0.077) == 976                                   # only the FIRST sweep is narrowed
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 4800
+        assert not zl.first_sequential and zl.next(None) == int(0.05 * 500_000 * (10 / 12) ** 2.5 * 0.0616) == 976                                   # only the FIRST sweep is narrowed
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 6000
         num, world, min_w, max_w, fixed = p.device_params()
         assert int(num / 50_000) == p.next(50_000) and (world, fixed, max_w) == (1, 0, 8192)
         assert bc.WavePolicy(100_000, fixed=1, m=30_000).sequential
         s = bc.WavePolicy(12_500, m=30_000, row_nnz=50, k=5, world=8)                           # 8 row shards
-        assert s.next(400_000) == int(0.04 * 30_000 * 12_500 / 2 / 50_000)                      # its share of the changed rows
+        assert s.next(400_000) == int(0.05 * 30_000 * 12_500 / 2 / 50_000)                      # its share of the changed rows
         with pytest.raises(ValueError):
             bc.WavePolicy(10, parity="sometimes")
     finally:

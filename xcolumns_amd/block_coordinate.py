@@ -79,14 +79,14 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 #
 # bca_parity = "per_sweep" (default): EVERY sweep within north_star's 1e-5 of the sequential reference --
 #     W_j = BETA * m * (50 / entries per row) * (5 / k)^2 * min(1, n k / 12 m)^2.5 * min(1, m / 30K)^0.5 * n / (2 * rows changed in sweep j-1)
-#     (half of the rows assumed before sweep 1), a thirteenth of it (less when m < 200 K) for the first sweep when the label
+#     (half of the rows assumed before sweep 1), a sixteenth of it (less when m < 200 K) for the first sweep when the label
 #     popularity is skewed (hot labels present); converged sweeps use the whole GPU.
 # bca_parity = "final": four times wider -- the utility after the LAST sweep is what is held to 1e-5
 #     (intermediate sweeps of a top-k start stay within ~5e-5), for callers that only use the result.
 # A changing row moves more labels the larger k is and the trajectories then settle in different, nearly
 # equivalent optima (k = 64, n = 6000, m = 900: 1.6e-4 in sweep 1 at the k = 5 width, 1.3e-5 with (5 / k)^1.5), hence (5 / k)^2.
-_BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.04"))
-_SKEWED_FIRST_SWEEP = 0.077
+_BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.05"))
+_SKEWED_FIRST_SWEEP = 0.0616
 _FINAL_PARITY_FACTOR = 4.0
 _STALE_BUDGET = float(os.environ["XCOLUMNS_BCA_STALE_BUDGET"]) if "XCOLUMNS_BCA_STALE_BUDGET" in os.environ else None
 _MIN_WAVES = 1
