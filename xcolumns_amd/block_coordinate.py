@@ -565,7 +565,7 @@ class BcaCsrEngine:
             from .distributed import exchange_changes, exchanges_for_sweep
             # the host runs one boundary behind the GPU: the newest changed-row count it has is sweep j - 2's
             # (identical on every rank -- it comes out of the all-reduced statistics -- so all ranks agree)
-            segments = min(exchanges_for_sweep(self.exchanges, self._changed_known, self.n_total, self.comm.world), max(1, n))
+            segments = exchanges_for_sweep(self.exchanges, self._changed_known, self.n_total, self.comm.world)
         self.exchanges_used = getattr(self, "exchanges_used", [])
         self.exchanges_used.append(segments)
         if segments <= 1:
@@ -589,11 +589,16 @@ class BcaCsrEngine:
             # (xc_bca_exchange_step) replaces the three of the blocking form.  A rank then misses the others' updates
             # of 1/2 .. 1 blocking segments (blocking: 0 .. 1): about the same staleness, no waiting.
             overlap = (os.environ.get("XCOLUMNS_BCA_EXCHANGE_OVERLAP", "1") != "0" and hasattr(self.comm, "all_reduce_async"))
-            parts = min(2 * segments, 16, max(1, n)) if overlap else segments
-            # a part is its own launch (ramp-up and drain ~10 us): a small shard is not cut finer than 16 K rows per
-            # part, except for the parts the iteration needs to contract (distributed.min_exchanges)
+            parts = min(2 * segments, 16) if overlap else segments
+            # A part is its own launch (ramp-up and drain ~10 us): a small shard is not cut finer than 16 K rows per
+            # part -- then in the blocking form (few parts, the waiting is cheap), and never below the number the
+            # iteration needs to contract (distributed.min_exchanges).  From the GLOBAL row count: every rank must cut
+            # its sweep into the same number of parts (the collectives pair up) and shard sizes differ.
             from .distributed import min_exchanges
-            parts = max(min(parts, max(1, n // 16384)), min(segments, min_exchanges(self.comm.world)))
+            fit = max(1, (self.n_total // self.comm.world) // 16384)
+            if parts > fit:
+                overlap = False
+                parts = max(min(segments, fit), min(segments, min_exchanges(self.comm.world)))
             self.exchanges_used[-1] = parts
             bounds = [n * s // parts for s in range(parts + 1)]
             pending = None
@@ -1066,12 +1071,12 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
     # changes every row in sweep 1 and keeps many rows moving for several sweeps (measured 1.0-1.1e-5 in sweep 1
     # at half the top-k width): a quarter of the width for the whole run
     normalize_first = n_u >= n_rows
-    calm = init_idx is None and maximize
+    calm = init_idx is None and maximize   # a minimisation starts from its worst point: every row changes
     parity = default_parity() if bca_parity is None else bca_parity
     policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if calm else 1.0,
                         m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.skewed,
                         parity=parity, scale=1.0 if calm else 0.25,
-                        first_sequential=init_idx is not None and not greedy and parity == "per_sweep" and normalize_first)
+                        first_sequential=not calm and not greedy and parity == "per_sweep" and normalize_first)
     try:
         run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                        policy, verbose, meta)
