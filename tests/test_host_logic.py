@@ -286,6 +286,10 @@ def test_wave_policy_rules():
         assert bc.WavePolicy(100_000, fixed=1, m=30_000).sequential
         s = bc.WavePolicy(12_500, m=30_000, row_nnz=50, k=5, world=8)                           # 8 row shards
         assert s.next(400_000) == int(0.05 * 30_000 * 12_500 / 2 / 50_000)                      # its share of the changed rows
+        g = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5)                                   # ~1 predicted row per label
+        assert g.sequential and g.next(None) == 1 and g.next(10) == 1
+        gf = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5, parity="final")
+        assert not gf.sequential and 1 < gf.next(None) < 400 and gf.next(10) <= 2 * 4 * 0.05 * 670_000 * (150_000 * 5 / 670_000 / 12) ** 2.5 * 0.5 + 1
         with pytest.raises(ValueError):
             bc.WavePolicy(10, parity="sometimes")
     finally:

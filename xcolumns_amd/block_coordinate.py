@@ -149,6 +149,13 @@ class WavePolicy:
             # ... and since the differences do not heal there, converging sweeps may not widen freely either: at most
             # twice the first sweep's width while a label holds fewer than four predicted rows (C3, third sweep at
             # 1.5x the first width: 9.2e-6; constant width 146: 8.6e-6, 3.8e-6, 6.1e-6, 4.1e-6, 3.1e-6)
+            if per_label < 2.0 and self.parity == "per_sweep" and not self.fixed:
+                # About ONE predicted row per label (150 K rows x 670 K labels): 35 / 19 / 55 wavefronts still ended a
+                # sweep at 8.0e-6 and 1.02e-5 in two of five runs, and nothing heals afterwards.  The reference itself
+                # moves by 1.2-3.8e-5 (standard deviation) there when only its visiting order changes, so its trajectory
+                # cannot be tracked to 1e-5 by anything but its own sequence: these shapes run the sequential sweep
+                # (exact; 0.25 s per sweep at C3) unless the caller asks for bca_parity="final" or a width.
+                self.fixed = 1
             if per_label < 4.0:
                 width *= 0.5     # three runs at 71 / 39 / 110 wavefronts ended sweep 3 at 2.9e-6, 8.7e-6, 9.0e-6: too close
                 self.num = width * self.n / 2.0
