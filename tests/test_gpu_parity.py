@@ -409,8 +409,10 @@ def test_bca_csr_long_ragged_rows_exact(oref, dtype):
         assert np.array_equal(Pg.indices, Po.indices)
         # concurrent mode on the same input: valid prediction, close utility
         Pc, mc = predict_using_bc_with_0approx(Y, fn_, k, skip_tn=skip_tn, seed=3, max_iters=3, tolerance=-1.0,
-                                               return_meta=True, bca_waves=8)
-        assert abs(mc["utilities"][-1] - mo["utilities"][-1]) < 1e-4
+                                               return_meta=True, bca_waves=4)
+        dc = np.abs(np.asarray(mc["utilities"]) - np.asarray(mo["utilities"]))
+        print("long ragged rows, 4 wavefronts on 500 rows:", dc)
+        assert dc.max() < 2e-5    # 0.8 % of this tiny matrix in flight, far beyond what the policy would allow (1 wavefront)
         assert (np.diff(Pc.indices.reshape(n, k), axis=1) > 0).all()
 
 
@@ -515,7 +517,7 @@ def test_bca_concurrent_arithmetic_all_metrics(oref, case):
                                            bca_waves=8)
     d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
     print(base, "concurrent(8 waves) vs sequential:", d)
-    assert d[-1] < 2e-5 and d.max() < 2e-4, (mg["utilities"], mo["utilities"])
+    assert d.max() < PER_SWEEP_TOL, (mg["utilities"], mo["utilities"])   # every sweep (measured <= 5e-6 with the commit protocol)
     same = (Pg.indices.reshape(n, k) == Po.indices.reshape(n, k)).all(axis=1).mean()
     assert same > 0.97, same
 
@@ -536,7 +538,7 @@ def test_bca_concurrent_arithmetic_kf_scaling(oref, entry):
     d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
     scale = max(1.0, abs(mo["utilities"][-1]))
     print(entry, d, mo["utilities"])
-    assert d[-1] < 2e-5 * scale and d.max() < 2e-4 * scale
+    assert d.max() < PER_SWEEP_TOL * scale
     same = (Pg.indices.reshape(n, k) == Po.indices.reshape(n, k)).all(axis=1).mean()
     assert same > 0.97, same
 
