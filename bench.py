@@ -594,6 +594,16 @@ def api_call_leg(Y, sweeps):
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         assert meta["iters"] == sweeps
+        if os.environ.get("XC_BENCH_API_PROFILE") == "1":      # where the host side of one call spends its time
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            f(inp, K, tolerance=-1.0, max_iters=sweeps, seed=ORDER_SEED, return_meta=True)
+            torch.cuda.synchronize()
+            pr.disable()
+            print(name, ["%.1f" % (t * 1e3) for t in times], file=sys.stderr)
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
         med = float(np.median(times[1:]))
         res[name] = {"ms": med * 1e3, "rows_per_s": n * sweeps / med, "ms_min": min(times[1:]) * 1e3,
                      "ms_max": max(times[1:]) * 1e3, "calls": len(times) - 1}

@@ -179,9 +179,13 @@ def test_topk_csr_long_rows_vs_oracle(oref):
 # confusion matrix
 # ---------------------------------------------------------------------------
 
+@pytest.mark.parametrize("bucketed", ["0", "1"])
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_confusion_golden(tag):
+def test_confusion_golden(tag, bucketed, monkeypatch):
+    """Both forms of the CSR kernel (one global atomic per contribution; counting sort by label bucket + LDS sums)
+    against the reference's outputs, incl. the padded-prediction quirk."""
     from xcolumns_amd.confusion_matrix import calculate_confusion_matrix
+    monkeypatch.setenv("XCOLUMNS_CONFUSION_BUCKETED", bucketed)
     z = G.load("confusion_" + tag)
     mats = {n: G.csr_from(z, n) for n in ("y", "p", "prand", "l")}
     for tname in ("y", "l"):
@@ -203,6 +207,31 @@ def test_confusion_golden(tag):
             assert Ct.tp.is_cuda
             assert np.allclose(np.stack([v.cpu().numpy() for v in Ct]), z[f"C_{tname}_pd_skip{int(skip_tn)}_norm0"],
                                rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_confusion_bucketed_vs_oracle_large(oref, dtype, monkeypatch):
+    """300 K x 200 K, ragged rows (some shorter than k: the reference's top-k pads them with column 0, unsorted),
+    several chunks and ~100 label buckets: the bucketed form, the atomic form and the oracle agree."""
+    from xcolumns_amd.confusion_matrix import calculate_confusion_matrix
+    from xcolumns_amd.weighted_prediction import predict_top_k
+    rng = np.random.default_rng(11)
+    n, m, k = 300_000, 200_000, 5
+    lens = rng.integers(0, 24, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = rng.integers(0, m, size=int(indptr[-1])).astype(np.int32)
+    Y = csr_matrix((rng.random(indptr[-1]).astype(dtype), cols, indptr), shape=(n, m))
+    Y.sum_duplicates()
+    Y.sort_indices()
+    P = predict_top_k(Y, k)
+    exp = np.stack(list(oref.calculate_confusion_matrix(Y, P, skip_tn=True)))[:3]
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("XCOLUMNS_CONFUSION_BUCKETED", mode)
+        C = calculate_confusion_matrix(Y, P, skip_tn=True, dtype=np.float64)
+        got[mode] = np.stack([C.tp, C.fp, C.fn])
+        assert np.allclose(got[mode], exp, rtol=1e-12, atol=1e-12), mode
+    assert np.allclose(got["0"], got["1"], rtol=1e-13, atol=1e-13)
 
 
 # ---------------------------------------------------------------------------

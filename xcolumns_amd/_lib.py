@@ -58,6 +58,10 @@ SIGNATURES = {
                               c_void_p, c_int, c_void_p]),
     "xc_confusion_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xc_confusion_csr_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(c_int64)]),
+    "xc_confusion_csr_bucketed": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
     "xc_confusion_dense": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "xc_bca_gather_pred_eta": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,

@@ -35,6 +35,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time as _time
 from time import time
 from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
@@ -780,37 +781,57 @@ class _OrderSource:
             self._jq = queue.Queue(maxsize=2)
             self._stop = threading.Event()
             self._error = None
+            self._trace = [] if os.environ.get("XCOLUMNS_ORDER_TRACE") == "1" else None   # per-stage host times
             self._jobs = []
             if self._fast is not None:
                 self._jobs.append(_OrderWorkers.submit(0, self._produce_draws))
             self._jobs.append(_OrderWorkers.submit(1, self._produce))
 
+    # Hand-over between the threads: blocking queue operations, woken by close() / a failing worker (which empty
+    # the queues and push a None) rather than by polling a flag -- a 20 ms poll was the larger part of a call on
+    # a 100 K-row matrix.  The long timeouts are a safety net only.
     def _put(self, q, item) -> bool:
-        while not self._stop.is_set():
+        while not self._stop.is_set() and self._error is None:
             try:
-                q.put(item, timeout=0.02)
+                q.put(item, timeout=0.25)
                 return True
             except Exception:
                 continue
         return False
 
     def _get(self, q):
-        while not self._stop.is_set():
-            if self._error is not None:
-                return None
+        while not self._stop.is_set() and self._error is None:
             try:
-                return q.get(timeout=0.02)
+                return q.get(timeout=0.25)       # None: woken to stop
             except Exception:
                 continue
         return None
 
+    def _wake(self):
+        """Unblock whoever waits on either queue: make room, then leave a None for the getters."""
+        for q in (self._q, self._jq):
+            try:
+                while True:
+                    q.get_nowait()
+            except Exception:
+                pass
+            try:
+                q.put_nowait(None)
+            except Exception:
+                pass
+
     def _produce_draws(self):
         try:
             while not self._stop.is_set():
-                if not self._put(self._jq, self._fast.draws()):
+                t0 = _time.perf_counter()
+                js = self._fast.draws()
+                if self._trace is not None:
+                    self._trace.append(("draws", _time.perf_counter() - t0))
+                if not self._put(self._jq, js):
                     break
         except BaseException as e:
             self._error = e
+            self._wake()
 
     def _produce(self):
         try:
@@ -834,10 +855,15 @@ class _OrderSource:
                 if done[slot] is not None:
                     done[slot].synchronize()          # its previous copy has left the pinned buffer
                 if self._fast is not None:
+                    t0 = _time.perf_counter()
                     js = self._get(self._jq)
                     if js is None:
                         break
+                    t1 = _time.perf_counter()
                     np.copyto(pinned[slot].numpy(), self._fast.apply(js))   # :418-419, the swaps of the int32 walk
+                    if self._trace is not None:
+                        self._trace.append(("wait_draws", t1 - t0))
+                        self._trace.append(("apply+copy", _time.perf_counter() - t1))
                 else:
                     self.rng.shuffle(self.order)      # :418-419 (GIL released)
                     np.copyto(pinned[slot].numpy(), self.order, casting="unsafe")
@@ -854,6 +880,7 @@ class _OrderSource:
                     ev.synchronize()
         except BaseException as e:                    # surfaced by next()
             self._error = e
+            self._wake()
 
     def next(self) -> Optional[torch.Tensor]:
         if not self.shuffle:
@@ -877,10 +904,19 @@ class _OrderSource:
         """Stop the workers' jobs (orders generated ahead of an early stop are dropped) and hand the workers back."""
         if self._threaded:
             self._stop.set()
+            deadline = _time.monotonic() + 10.0
             for done in self._jobs:
-                done.wait(timeout=10.0)
+                self._wake()
+                while not done.wait(timeout=0.001) and _time.monotonic() < deadline:
+                    self._wake()
             self._threaded = False
             _OrderWorkers.release()
+            if self._trace:
+                import sys
+                by = {}
+                for name, t in self._trace:
+                    by.setdefault(name, []).append(t * 1e3)
+                print("order workers, ms per order:", {k_: [round(x, 2) for x in v] for k_, v in by.items()}, file=sys.stderr)
 
     def __del__(self):
         try:

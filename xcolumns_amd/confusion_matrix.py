@@ -13,6 +13,8 @@ them, SURVEY.md section 8 a-10 vi) and come back on the input's device.
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import Optional, Union
 
 import numpy as np
@@ -99,9 +101,29 @@ class ConfusionMatrix:
 # device-level
 # ---------------------------------------------------------------------------
 
+# Measured on MI355X (profiles/r02_confusion_timing.txt): the bucketed form is NOT faster yet -- 2.9 ms against 2.4 ms
+# at 1 M x 500 K x 50 (its two row passes cost 0.8 ms each before any sorting), 3.0 against 1.85 ms at the C5 shape --
+# so nothing selects it by default; XCOLUMNS_CONFUSION_BUCKETED=1 forces it (tests keep it pinned to the same goldens).
+_BUCKETED_MIN_ITEMS = None
+_BUCKETED_MAX_LABELS = 16384 * 2048   # XC_CF_BUCKETS_MAX x XC_CF_BUCKET_LABELS_MAX
+
+
 def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR) -> torch.Tensor:
     """tp | fp | fn as a (3, m) float64 tensor on the GPU."""
     out = torch.zeros((3, t.m), dtype=torch.float64, device=t.data.device)
+    # many contributions: counting-sort them by label bucket and sum in LDS instead of one global atomic each
+    # (xc_confusion_csr_bucketed; the memory side retires ~23.5 G scattered adds/s).  XCOLUMNS_CONFUSION_BUCKETED=0/1 forces.
+    items = 2 * p.nnz + t.nnz
+    forced = os.environ.get("XCOLUMNS_CONFUSION_BUCKETED")
+    fits = items < 2 ** 31 and t.m <= _BUCKETED_MAX_LABELS and t.n > 0
+    if fits and (forced == "1" or (forced is None and _BUCKETED_MIN_ITEMS is not None and items >= _BUCKETED_MIN_ITEMS)):
+        nbytes = ctypes.c_int64(0)
+        _lib.call("xc_confusion_csr_workspace_bytes", t.n, t.m, t.nnz, p.nnz, t.code, ctypes.byref(nbytes))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=t.data.device)
+        _lib.call("xc_confusion_csr_bucketed", t.n, t.m, D.ptr(t.indptr), D.ptr(t.indices), D.ptr(t.data),
+                  D.ptr(p.indptr), D.ptr(p.indices), D.ptr(p.data), t.code, t.nnz, p.nnz, D.ptr(out[0]), D.ptr(out[1]),
+                  D.ptr(out[2]), D.ptr(ws), D.stream())
+        return out
     _lib.call("xc_confusion_csr", t.n, t.m, D.ptr(t.indptr), D.ptr(t.indices), D.ptr(t.data),
               D.ptr(p.indptr), D.ptr(p.indices), D.ptr(p.data), t.code, D.ptr(out[0]), D.ptr(out[1]),
               D.ptr(out[2]), D.stream())
