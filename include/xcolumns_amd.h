@@ -337,6 +337,20 @@ int xc_bca_time_next_sweep(void *start, void *stop);
  *   0            none. */
 int xc_bca_set_validation(int mode);
 
+/* Where a pipelined concurrent sweep leaves the statistics of its new prediction (block_coordinate.py:465-467
+ * recomputes them from scratch at every boundary).  on = 1 (default): with the commit protocol on float32
+ * shadow records, every committed change is pushed into the float64 records tpfp -- exact float64 sums of
+ * float32 values, atomics for the rows that change only -- and the boundary reads them there.  on = 0: every
+ * row adds its k labels to `acc` (from scratch, as round 1 did: one 16-byte atomic per predicted label, 19 % of
+ * a converged sweep at 1 M x 500 K).  xc_bca_plan_delta: does this plan's next pipelined sweep use the first form. */
+int xc_bca_set_acc_delta(int on);
+int xc_bca_plan_delta(void *plan);
+/* Row shards with the first form: d[0..m2) = tpfp - base, d[m2] = count[0] (this rank's changed rows) before the
+ * all-reduce of d; tpfp = base = base + d, count[0] = d[m2] after it (m2 = 2 m). */
+int xc_bca_delta_pack(int64_t m2, const double *tpfp, const double *base, const double *count, double *d,
+                      void *stream);
+int xc_bca_delta_unpack(int64_t m2, double *tpfp, double *base, double *count, const double *d, void *stream);
+
 /* Two constants of the concurrent sweep (process-wide, studies; negative = leave as is):
  *   conflict_rel     commit protocol: a returned record that differs from the scored one by less than this
  *                    share of (tp + fp) does not count as a conflict (default 1/512: one other row changing a

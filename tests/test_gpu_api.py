@@ -176,6 +176,30 @@ def test_deterministic_concurrent_mode(oref, zipf):
     assert np.array_equal(a.indices, b.indices)
 
 
+@pytest.mark.parametrize("delta", ["1", "0"])
+@pytest.mark.parametrize("zipf", [False, True])
+def test_boundary_statistics_are_those_of_the_prediction(oref, zipf, delta, monkeypatch):
+    """The reference recomputes the confusion matrix from scratch at every sweep boundary (block_coordinate.py:465-467).
+    The pipelined sweeps either rebuild it in `acc` (XCOLUMNS_BCA_ACC_DELTA=0) or push every committed change into
+    the float64 records (default; hot labels through a float64 LDS table): both ways the utility reported after
+    the last sweep is the utility of the returned prediction computed from scratch, and every sweep holds the bar."""
+    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+    from xcolumns_amd.synthetic import make_csr
+
+    monkeypatch.setenv("XCOLUMNS_BCA_ACC_DELTA", delta)
+    n, m, k = 100_000, 30_000, 5
+    Y = make_csr(n, m, 50, seed=20240001, zipf=zipf, k=k)
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=6, tolerance=-1.0)
+    P, mg = f(Y, k, seed=13, max_iters=6, tolerance=-1.0, return_meta=True)
+    tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, P, skip_tn=True)
+    u = oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n)
+    d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print("acc_delta", delta, "zipf", zipf, "|reported - from scratch|", abs(u - mg["utilities"][-1]), "per sweep vs oracle", d)
+    assert abs(u - mg["utilities"][-1]) < 1e-11
+    assert d.max() < 1e-5
+
+
 def test_final_parity_policy(oref):
     """bca_parity="final": wider sweeps than the default (four times), the utility after the LAST sweep within 1e-5 of
     the sequential oracle (intermediate sweeps may sit a few 1e-5 away); "per_sweep" (default) holds every sweep."""
@@ -249,5 +273,5 @@ def test_scatter_sum_against_index_add(m):
         else:
             want = torch.zeros(m, dtype=torch.float64, device=dev)
             want.index_add_(0, idx.long(), val.double())
-        torch.testing.assert_close(out[:-1], want, rtol=0, atol=1e-9)
+        torch.testing.assert_close(out[:-1], want, rtol=1e-13, atol=1e-9)   # float64 summation order
         assert float(out[-1]) == -7.0                       # nothing written past the last label

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../xcolumns_amd/csrc"
 mkdir -p ../../tools/_build/stamps_obj
-for f in xc_lib xc_topk xc_confusion xc_bca xc_dense xc_fw; do
+for f in xc_lib xc_topk xc_confusion xc_bca xc_dense xc_fw xc_coverage xc_order xc_bca_det xc_scatter; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DXC_STAMPS \
       -I../../include -I. -c $f.hip -o ../../tools/_build/stamps_obj/$f.o &
 done

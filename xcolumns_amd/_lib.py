@@ -113,6 +113,10 @@ SIGNATURES = {
     "xc_bca_plan_boundary": (c_int, [c_void_p, c_int64, c_double, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                      c_void_p]),
     "xc_bca_set_validation": (c_int, [c_int]),
+    "xc_bca_set_acc_delta": (c_int, [c_int]),
+    "xc_bca_plan_delta": (c_int, [c_void_p]),
+    "xc_bca_delta_pack": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xc_bca_delta_unpack": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_set_tuning": (c_int, [c_double, c_double]),
     "xc_dense_pred_to_fixed": (c_int, [c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p]),

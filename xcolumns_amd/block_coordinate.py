@@ -309,6 +309,9 @@ class BcaCsrEngine:
                 self.hot_slot[labels.long()] = torch.arange(1, n_hot + 1, dtype=torch.uint8, device=dev)
         # from-scratch {tp, fp} of a sweep boundary; slot 2m carries the changed-row count
         self.acc = torch.zeros(2 * m + 1, dtype=torch.float64, device=dev)
+        # pipelined concurrent sweeps push their committed changes into the float64 records instead of rebuilding
+        # `acc` (xc_bca_set_acc_delta; XCOLUMNS_BCA_ACC_DELTA=0 = from scratch in every sweep, as round 1 did)
+        _lib.call("xc_bca_set_acc_delta", int(os.environ.get("XCOLUMNS_BCA_ACC_DELTA", "1") != "0"))
         # sharded rows: exchanges of the ranks' changes per sweep (1 = only the all-reduce of the
         # from-scratch statistics at the sweep boundary, the north-star scheme)
         # sweep), S > 1 = S - 1 more all-reduces of the float32 records inside the sweep, "auto" = several in
@@ -553,11 +556,22 @@ class BcaCsrEngine:
             self._pipe_seq = 0.0      # grows by one per boundary over the engine's lifetime
             self._seq_of = {}
         num, world, min_w, max_w, fixed = policy.device_params()
+        if self._delta_sharded():
+            # the statistics every rank holds now (all-reduced, committed): the base of the sweeps' changes
+            if getattr(self, "_tpfp_base", None) is None:
+                self._tpfp_base = torch.empty_like(self.tpfp)
+                self._delta_buf = torch.empty(2 * self.csr.m + 1, dtype=torch.float64, device=self.dev)
+            self._tpfp_base.copy_(self.tpfp)
         self._changed_known = None
         self._pipe_max_waves = max(2, max_w)
         _lib.call("xc_bca_pipeline_begin", D.ptr(self._ctrl), float(old_utility_sum), float(tolerance), float(divisor),
                   int(bool(maximize)), float(num), int(world), int(min_w), int(max_w), int(fixed),
                   int(max(1, min(first_waves, max_w))), D.stream())
+
+    def _delta_sharded(self) -> bool:
+        """Row shards whose pipelined sweeps leave their changes in the float64 records (xc_bca_set_acc_delta)
+        instead of rebuilding `acc` from scratch."""
+        return self.comm is not None and bool(_lib.load().xc_bca_plan_delta(self._plan_handle()))
 
     def pipeline_step(self, order: Optional[torch.Tensor], j: int, n_norm_utility: int):
         """Enqueue sweep j and its boundary; returns at once.  The sweep runs only if the rule has
@@ -626,7 +640,17 @@ class BcaCsrEngine:
             if pending is not None:
                 pending.wait()   # the last publication is superseded by the boundary's from-scratch statistics
         if self.comm is not None:
-            self.comm.all_reduce(self.acc)
+            if self._delta_sharded():
+                # the sweep pushed this rank's changes into its float64 records: what the ranks exchange is
+                # (records - the statistics agreed at the last boundary), exact in float64, same 2m + 1 doubles
+                m2 = 2 * self.csr.m
+                _lib.call("xc_bca_delta_pack", m2, D.ptr(self.tpfp), D.ptr(self._tpfp_base), D.ptr(self.acc[m2:]),
+                          D.ptr(self._delta_buf), D.stream())
+                self.comm.all_reduce(self._delta_buf)
+                _lib.call("xc_bca_delta_unpack", m2, D.ptr(self.tpfp), D.ptr(self._tpfp_base), D.ptr(self.acc[m2:]),
+                          D.ptr(self._delta_buf), D.stream())
+            else:
+                self.comm.all_reduce(self.acc)
         slot = j % _lib.XC_CTRL_RING_SLOTS
         self._pipe_seq += 1.0
         self._seq_of[slot] = self._pipe_seq

@@ -66,6 +66,9 @@ struct SweepParams {
                             // (concurrent sweeps only: the exact mode reads the float64 s_entry)
     const int32_t *hot_labels; // optional [64] (with packed): label id of hot slot h = 1..63, -1 = unused
     double *acc;            // optional [2m + 1]: from-scratch {tp, fp} of the NEW prediction, [2m] += changed rows
+    int acc_delta;          // with acc, commit protocol only: do NOT rebuild the statistics from scratch in `acc`;
+                            // push every committed change into the float64 records `tpfp` instead (a sweep that
+                            // gathers the float32 shadow never reads them) -- the boundary takes them from there
     int64_t m;
     unsigned tpfp_bytes;
     xc_metric metric;      // as given (EXACT path)
@@ -167,8 +170,13 @@ __device__ __forceinline__ void load_row(const SweepParams<T> &P, int s, int r, 
 // SHADOW (only with !EXACT, never greedy): gather the float32 copy of the records.
 // PACKED (float32 scores, never greedy): the row streams come interleaved from `packed`.
 // HOT (with SHADOW, PACKED and acc): deltas to the hot labels are batched per workgroup.
+#ifdef XC_SWEEP_WAVES_PER_EU /* experiment builds (tools/build_variant.sh): trade spills for resident wavefronts */
+#define XC_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(XC_SWEEP_WAVES_PER_EU, 8)))
+#else
+#define XC_SWEEP_OCC
+#endif
 template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
-__global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> P) {
+__global__ __launch_bounds__(XC_BLOCK) XC_SWEEP_OCC void bca_sweep_csr_kernel(SweepParams<T> P) {
     const int lane = lane_id();
     const int wave = blockIdx.x * (XC_BLOCK / XC_WAVE) + (threadIdx.x >> 6);
     // hot-label delta table of the workgroup (see flush_hot below): zeroed before any wave leaves
@@ -178,11 +186,15 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     // 63 lines every publication of every workgroup rewrites -- 17 M gathers of lines that the atomics keep
     // dropping from the L2s were the largest single cost of a first sweep on Zipf popularity.
     __shared__ float s_hotrec[XC_WAVE][2];
+    // acc_delta: the workgroup's changes of the hot labels in float64, pushed into tpfp once, when it ends
+    __shared__ double s_hot64[XC_WAVE][2];
     __shared__ int s_hot_ticks, s_hot_done;
     if (HOT) {
         if (threadIdx.x < XC_WAVE) {
             s_hot[threadIdx.x][0] = 0.0f;
             s_hot[threadIdx.x][1] = 0.0f;
+            s_hot64[threadIdx.x][0] = 0.0;
+            s_hot64[threadIdx.x][1] = 0.0;
             const int hl = P.hot_labels[threadIdx.x];
             s_hotrec[threadIdx.x][0] = hl >= 0 ? __hip_atomic_load(P.shadow + (int64_t)hl * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
             s_hotrec[threadIdx.x][1] = hl >= 0 ? __hip_atomic_load(P.shadow + (int64_t)hl * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
@@ -203,6 +215,10 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
     const double nn = P.nn;
     const bool greedy = P.greedy != 0;
     const bool skip_tn = P.skip_tn != 0;
+    const bool commit_mode = !EXACT && !greedy && P.validate == 2;
+    // does this sweep rebuild the new prediction's statistics from scratch in `acc` (every row adds its k labels),
+    // or push the committed changes into the float64 records (acc_delta: changing rows only)
+    const bool acc_scratch = P.acc != nullptr && !(P.acc_delta != 0 && commit_mode);
     const int64_t W = n_walk;
     const int64_t last = P.n_order - 1;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.tpfp, 0, P.tpfp_bytes, XC_RSRC_WORD3);
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         load_row<T, CH, PACKED>(P, s1, e1 - s1, lane, nxt);
         const int s2 = P.indptr[row2], e2 = P.indptr[row2 + 1];
         const int row3 = row_at(pos + 3 * W);
-        if (P.acc) flush_pending(); // the previous row's contribution to acc (younger than the gathers)
+        if (acc_scratch) flush_pending(); // the previous row's contribution to acc (younger than the gathers)
         XC_STAMP(0); // issue gathers + prefetches
 
         // ---- membership of the candidates in the current prediction comes with
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         if (P.orphans && !greedy && lane < k) {
             const int oid = P.orphans[row * k + lane];
             if (oid >= 0) {
-                if (!(SHADOW && P.acc)) atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
+                if (!(SHADOW && acc_scratch)) atomic_add_f64(P.tpfp + (int64_t)oid * 2 + 1, -1.0);
                 if (P.shadow) atomic_add_f32(P.shadow + (int64_t)oid * 2 + 1, -1.0f);
             }
         }
@@ -376,8 +392,18 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         for (int c = 0; c < CH; ++c) in_cur[c] = in_old[c];
         int n_cur = n_old;
         bool row_changed = false;
-        const bool commit_mode = !EXACT && !greedy && P.validate == 2;
         const int kk = r < k ? r : k;
+        // The records are first USED here, in straight-line code: the wait hipcc puts in front of this is the
+        // exact one (vmcnt = the prefetches issued after the gathers).  Inside the retry loop, where a second
+        // pass reads re-gathered records, its bookkeeping merges the two paths into vmcnt(0) -- every row
+        // would also wait for the next row's stream loads and for the previous row's `acc` atomics, both
+        // younger than the gathers and both slower.
+        double tp_now[CH], fp_now[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            tp_now[c] = SHADOW ? (double)rec32[c].x : rec64[c].x;
+            fp_now[c] = SHADOW ? (double)rec32[c].y : rec64[c].y;
+        }
         for (int attempt = 0;; ++attempt) {
         // ---- gains (block_coordinate.py:248-282) ----
         unsigned long long key[CH];
@@ -389,8 +415,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                 const T om = (T)1 - e; // (1 - t_data) in the input dtype, :253
                 const double ed = (double)e;
                 const double omd = (double)om;
-                double tpc = SHADOW ? (double)rec32[c].x : rec64[c].x;
-                double fpc = SHADOW ? (double)rec32[c].y : rec64[c].y;
+                double tpc = tp_now[c];
+                double fpc = fp_now[c];
                 double scc = sc[c];
                 // statistics without this row (:243-246, done in registers)
                 if (in_cur[c]) {
@@ -541,13 +567,19 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                         (void)__hip_atomic_fetch_add(&s_hot[cur.hot[c]][1], (float)(sgn * omd), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!acc_scratch) { // exact float64 sums for the records, one push per workgroup at its end
+                            (void)__hip_atomic_fetch_add(&s_hot64[cur.hot[c]][0], sgn * ed, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                            (void)__hip_atomic_fetch_add(&s_hot64[cur.hot[c]][1], sgn * omd, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     } else if (SHADOW) {
                         float *sh = P.shadow + (int64_t)cur.idx[c] * 2;
                         const float was_tp = atomic_add_ret_f32(sh + 0, (float)(sgn * ed));
                         const float was_fp = atomic_add_ret_f32(sh + 1, (float)(sgn * omd));
                         conflict = conflict || (fabsf(was_tp - rec32[c].x) + fabsf(was_fp - rec32[c].y) >
                                                 P.conflict_rel * (rec32[c].x + rec32[c].y));
-                        if (!P.acc) { // the float64 records are read again before a commit kernel rewrites them
+                        if (!acc_scratch) { // the float64 records are what the boundary reads (no acc, or acc_delta)
                             atomic_add_f64(P.tpfp + (int64_t)cur.idx[c] * 2, sgn * ed);
                             atomic_add_f64(P.tpfp + (int64_t)cur.idx[c] * 2 + 1, sgn * omd);
                         }
@@ -598,6 +630,8 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
             else
                 rec64[c] = __builtin_bit_cast(
                     double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur.idx[c] * 16, 0, XC_CPOL_SC1));
+            tp_now[c] = SHADOW ? (double)rec32[c].x : rec64[c].x;
+            fp_now[c] = SHADOW ? (double)rec32[c].y : rec64[c].y;
         }
         } // retry
         if (commit_mode) { // in_new == in_cur == what memory holds; did the row end where it started?
@@ -611,7 +645,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
         // tp / fp of the new prediction summed over ALL rows) is accumulated row by row
         // instead of by a separate pass over the prediction afterwards; the atomics
         // themselves go out in the next iteration (flush_pending).
-        if (P.acc) {
+        if (acc_scratch) {
             int nsel = 0;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -677,7 +711,7 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
                         // a sweep that gathers the shadow AND accumulates the boundary's from-scratch
                         // statistics never reads the float64 records before the commit kernel
                         // overwrites them from `acc`: their delta atomics would be dead work
-                        if (!(SHADOW && P.acc)) {
+                        if (!(SHADOW && acc_scratch)) {
                             atomic_add_f64(st + 0, sgn * ed);
                             atomic_add_f64(st + 1, sgn * omd);
                         }
@@ -723,11 +757,18 @@ __global__ __launch_bounds__(XC_BLOCK) void bca_sweep_csr_kernel(SweepParams<T> 
 #endif
         XC_STAMP(5); // prefetch landing
     }
-    if (P.acc) flush_pending();
+    if (acc_scratch) flush_pending();
     if (hot_on) { // the last wave of the workgroup to finish publishes what is left
         int done = 0;
         if (lane == 0) done = __hip_atomic_fetch_add(&s_hot_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_amdgcn_readfirstlane(done) == waves_here - 1) flush_hot();
+        if (__builtin_amdgcn_readfirstlane(done) == waves_here - 1) {
+            flush_hot();
+            if (!acc_scratch && my_hot_label >= 0) {
+                const double a = s_hot64[lane][0], b = s_hot64[lane][1];
+                if (a != 0.0) atomic_add_f64(P.tpfp + (int64_t)my_hot_label * 2, a);
+                if (b != 0.0) atomic_add_f64(P.tpfp + (int64_t)my_hot_label * 2 + 1, b);
+            }
+        }
     }
 #ifdef XC_STAMPS
     if (P.stamps && lane == 0)
@@ -841,7 +882,7 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
     double sum = 0.0;
     for (int64_t j = j0 + threadIdx.x; j < j1; j += XC_BLOCK) {
         double tp, fp;
-        if (acc) {
+        if (acc && clear_acc != 2) {
             tp = acc[2 * j];
             fp = acc[2 * j + 1];
             tpfp[2 * j] = tp;
@@ -857,6 +898,10 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
         } else {
             tp = tpfp[2 * j];
             fp = tpfp[2 * j + 1];
+            if (acc && shadow) { // clear_acc == 2: the sweep pushed its changes into tpfp; the float32 copy follows
+                shadow[2 * j] = (float)tp;
+                shadow[2 * j + 1] = (float)fp;
+            }
         }
         const double sc = colsum[j];
         const double fn = sc - tp;
@@ -1042,6 +1087,7 @@ static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stam
 // one-shot HIP events recorded tightly around the NEXT sweep launch (xc_bca_time_next_sweep)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_validate = 2;                           // xc_bca_set_validation: 2 = commit protocol
+static int g_acc_delta = 1;                          // xc_bca_set_acc_delta: pipelined sweeps push changes instead of rebuilding acc
 static float g_conflict_rel = 1.0f / 512.0f;         // xc_bca_set_tuning
 static float g_hot_unpublished = 0.05f;              // xc_bca_set_tuning: share of the rows whose hot-label deltas may be unpublished
 
@@ -1101,6 +1147,26 @@ static void launch_sweep(const SweepParams<float> &P, int ch, hipStream_t st) {
 
 static void launch_sweep(const SweepParams<double> &P, int ch, hipStream_t st) {
     launch_sweep_mode<double, false>(P, ch, st);
+}
+
+// Row shards with acc_delta: a rank's float64 records hold the statistics all ranks agreed on at the last
+// boundary (`base`) plus what ITS rows changed since.  d <- records - base (exact: sums of float32 values in
+// float64), d[m2] <- this rank's changed-row count; after the all-reduce of d, records = base <- base + d.
+__global__ __launch_bounds__(XC_BLOCK) void delta_pack_kernel(int64_t m2, const double *tpfp, const double *base,
+                                                              const double *count, double *d) {
+    for (int64_t i = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; i < m2; i += (int64_t)gridDim.x * XC_BLOCK)
+        d[i] = tpfp[i] - base[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) d[m2] = count[0];
+}
+
+__global__ __launch_bounds__(XC_BLOCK) void delta_unpack_kernel(int64_t m2, double *tpfp, double *base, double *count,
+                                                                const double *d) {
+    for (int64_t i = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; i < m2; i += (int64_t)gridDim.x * XC_BLOCK) {
+        const double v = base[i] + d[i];
+        tpfp[i] = v;
+        base[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) count[0] = d[m2];
 }
 
 static int grid_for(int64_t n_items) {
@@ -1257,7 +1323,7 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
                           int32_t *pred_indices, void *pred_eta, uint8_t *sel, const int32_t *orphans, int k,
                           int64_t m, double *tpfp, float *shadow, double *colsum, const double *s_entry, void *packed,
                           const int32_t *hot_labels, double *acc, const xc_metric *metric_host, int maximize, int greedy,
-                          int skip_tn, int n_waves, int64_t *changed, const double *ctrl, void *stream) {
+                          int skip_tn, int n_waves, int64_t *changed, const double *ctrl, int acc_delta, void *stream) {
     if (n_order < 0 || n_norm < 1 || m < 1 || !indptr || !pred_indices || !pred_eta || !sel || !tpfp || !colsum ||
         !metric_host)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_sweep_csr: NULL pointer or bad size");
@@ -1284,7 +1350,7 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
     if (dtype == XC_F32) {
         xc::SweepParams<float> P{n_order, order, indptr, indices, static_cast<const float *>(data), pred_indices,
                                  static_cast<float *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
-                                 static_cast<xc::pack3_t *>(packed), packed ? hot_labels : nullptr, acc, m,
+                                 static_cast<xc::pack3_t *>(packed), packed ? hot_labels : nullptr, acc, acc_delta, m,
                                  (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                  (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate, xc::g_hot_unpublished, xc::g_conflict_rel,
                                  reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
@@ -1292,7 +1358,7 @@ static int sweep_csr_impl(int64_t n_order, const int32_t *order, int64_t n_norm,
     } else {
         xc::SweepParams<double> P{n_order, order, indptr, indices, static_cast<const double *>(data), pred_indices,
                                   static_cast<double *>(pred_eta), sel, orphans, k, tpfp, shadow, colsum, greedy ? nullptr : s_entry,
-                                  nullptr, nullptr, acc, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
+                                  nullptr, nullptr, acc, acc_delta, m, (unsigned)(m * 16), *metric_host, fast, (double)n_norm,
                                   (double)n_norm, maximize, greedy, skip_tn, n_waves, xc::g_validate, xc::g_hot_unpublished, xc::g_conflict_rel,
                                   reinterpret_cast<unsigned long long *>(changed), xc::g_stamp_buffer, ctrl};
         xc::launch_sweep(P, ch, st);
@@ -1309,7 +1375,7 @@ int xc_bca_sweep_csr(int64_t n_order, const int32_t *order, int64_t n_norm, cons
                      int skip_tn, int n_waves, int64_t *changed, void *stream) {
     return sweep_csr_impl(n_order, order, n_norm, indptr, indices, data, dtype, max_row_nnz, pred_indices, pred_eta,
                           sel, orphans, k, m, tpfp, shadow, colsum, s_entry, packed, hot_labels, acc, metric_host,
-                          maximize, greedy, skip_tn, n_waves, changed, nullptr, stream);
+                          maximize, greedy, skip_tn, n_waves, changed, nullptr, 0, stream);
 }
 
 // ---- measurement helpers (bench.py): HIP events owned by the library ---------------
@@ -1350,6 +1416,12 @@ int xc_bca_set_validation(int mode) {
     return XC_OK;
 }
 
+int xc_bca_set_acc_delta(int on) {
+    xc::g_acc_delta = on ? 1 : 0;
+    return XC_OK;
+}
+
+
 // Diagnostic builds (-DXC_STAMPS) only: device buffer of 8 uint64 phase-cycle sums.
 // Not part of include/xcolumns_amd.h; the shipped library ignores the pointer.
 int xc_debug_set_stamp_buffer(void *buf) {
@@ -1375,7 +1447,16 @@ struct xc_bca_plan_s {
     double *acc, *partials;
     xc_metric gain_metric, utility_metric;
     int maximize, skip_tn;
+    int last_delta; // did the last pipelined sweep leave its changes in tpfp (acc_delta) rather than rebuild acc
 };
+
+// A pipelined sweep leaves the statistics of the new prediction either rebuilt from scratch in `acc` (every row
+// adds its k labels: one 16-byte atomic each, 19 % of a converged sweep at 1 M x 500 K) or, with the commit
+// protocol on float32 shadow records, as the committed changes pushed into the float64 records -- exact float64
+// sums of float32 values either way, the second with atomics for the rows that CHANGE only.
+static int plan_delta(const xc_bca_plan_s *p) {
+    return xc::g_acc_delta && xc::g_validate == 2 && p->shadow != nullptr && p->acc != nullptr;
+}
 
 int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total, const int32_t *indptr,
                        const int32_t *indices, const void *data, int dtype, int max_row_nnz, int k,
@@ -1386,13 +1467,31 @@ int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total, const
     if (!plan || !gain_metric || !utility_metric) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_create: NULL pointer");
     xc_bca_plan_s *p = new xc_bca_plan_s{n, m, n_total, indptr, indices, data, dtype, max_row_nnz, k, pred_indices,
                                          pred_eta, sel, tpfp, shadow, colsum, s_entry, packed, hot_labels, acc, partials, *gain_metric,
-                                         *utility_metric, maximize, skip_tn};
+                                         *utility_metric, maximize, skip_tn, 0};
     *plan = p;
     return XC_OK;
 }
 
 int xc_bca_plan_destroy(void *plan) {
     delete static_cast<xc_bca_plan_s *>(plan);
+    return XC_OK;
+}
+
+int xc_bca_plan_delta(void *plan) { return plan ? plan_delta(static_cast<const xc_bca_plan_s *>(plan)) : 0; }
+
+int xc_bca_delta_pack(int64_t m2, const double *tpfp, const double *base, const double *count, double *d, void *stream) {
+    if (m2 < 1 || !tpfp || !base || !count || !d) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_delta_pack: bad argument");
+    hipLaunchKernelGGL(xc::delta_pack_kernel, dim3(xc::grid_for(m2)), dim3(XC_BLOCK), 0, xc::as_stream(stream), m2, tpfp, base,
+                       count, d);
+    XC_CHECK_LAUNCH("delta_pack_kernel");
+    return XC_OK;
+}
+
+int xc_bca_delta_unpack(int64_t m2, double *tpfp, double *base, double *count, const double *d, void *stream) {
+    if (m2 < 1 || !tpfp || !base || !count || !d) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_delta_unpack: bad argument");
+    hipLaunchKernelGGL(xc::delta_unpack_kernel, dim3(xc::grid_for(m2)), dim3(XC_BLOCK), 0, xc::as_stream(stream), m2, tpfp, base,
+                       count, d);
+    XC_CHECK_LAUNCH("delta_unpack_kernel");
     return XC_OK;
 }
 
@@ -1433,13 +1532,15 @@ int xc_bca_plan_sweep_pipelined(void *plan, const int32_t *order, int64_t first,
                                 int max_waves, const double *ctrl, void *stream) {
     if (!plan || !ctrl || max_waves < 2)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep_pipelined: bad argument");
-    const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
+    xc_bca_plan_s *p = static_cast<xc_bca_plan_s *>(plan);
     if (first < 0 || count < 0 || first + count > p->n || (!order && (first != 0 || count != p->n)))
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_sweep_pipelined: bad segment (a partial segment needs `order`)");
+    // the boundary that follows must read the statistics where this sweep leaves them
+    p->last_delta = plan_delta(p);
     return sweep_csr_impl(count, order ? order + first : nullptr, p->n_total, p->indptr, p->indices, p->data, p->dtype, p->max_row_nnz,
                           p->pred_indices, p->pred_eta, p->sel, nullptr, p->k, p->m, p->tpfp, p->shadow, p->colsum,
                           p->s_entry, use_packed ? p->packed : nullptr, p->hot_labels, p->acc, &p->gain_metric,
-                          p->maximize, 0, p->skip_tn, max_waves, nullptr, ctrl, stream);
+                          p->maximize, 0, p->skip_tn, max_waves, nullptr, ctrl, p->last_delta, stream);
 }
 
 int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_counted, int skip_tn, double *ctrl,
@@ -1447,7 +1548,7 @@ int xc_bca_plan_boundary_pipelined(void *plan, int64_t n_norm_utility, double n_
     if (!plan || !ctrl || slot < 0 || slot >= XC_CTRL_RING_SLOTS)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_plan_boundary_pipelined: bad argument");
     const xc_bca_plan_s *p = static_cast<const xc_bca_plan_s *>(plan);
-    int rc = commit_utility_impl(p->m, n_norm_utility, n_counted, p->acc, 1, p->tpfp, p->shadow, p->colsum,
+    int rc = commit_utility_impl(p->m, n_norm_utility, n_counted, p->acc, p->last_delta ? 2 : 1, p->tpfp, p->shadow, p->colsum,
                                  &p->utility_metric, skip_tn, p->partials, ctrl, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(xc::bca_boundary_finish_kernel, dim3(1), dim3(XC_UTILITY_PARTIALS / 2), 0, xc::as_stream(stream),
