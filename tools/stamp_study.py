@@ -25,7 +25,8 @@ from xcolumns_amd.synthetic import make_csr  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 30_000
 waves_list = [int(x) for x in sys.argv[3:]] or [390, 1562, 8192]
-Y = make_csr(n, m, 50, seed=20240001)
+zipf = os.environ.get("XC_STAMP_ZIPF") == "1"
+Y = make_csr(n, m, 50, seed=20240001, zipf=zipf, k=5)
 dev = D.require_gpu()
 lib = _lib.load()
 lib.xc_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
@@ -33,7 +34,7 @@ stamps = torch.zeros(8, dtype=torch.int64, device=dev)
 lib.xc_debug_set_stamp_buffer(ctypes.c_void_p(stamps.data_ptr()))
 csr = D.DeviceCSR.from_scipy(Y, dev)
 spec = MetricSpec(base=_lib.XC_M_FBETA)
-names = ["issue gathers+prefetch", "membership", "wait gathers + gains", "top-k bisection", "stores+atomics",
+names = ["issue gathers+prefetch", "membership", "wait gathers + gains", "top-k + commit", "stores+atomics",
          "prefetch landing/rotate"]
 rng = np.random.default_rng(13)
 order = np.arange(n)

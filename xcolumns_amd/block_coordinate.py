@@ -296,7 +296,7 @@ class BcaCsrEngine:
             # most frequent first, ties by label id: the same table whatever order the kernel listed them in
             pairs = pairs[np.lexsort((pairs[:, 0], -pairs[:, 1]))]
             self.skewed = n_found > 0
-            hot = pairs[pairs[:, 1] >= hot_min][:63]
+            hot = pairs[pairs[:, 1] >= hot_min][:max(0, min(63, int(os.environ.get("XCOLUMNS_BCA_HOT_MAX", "63"))))]
             n_hot = int(hot.shape[0])
             labels = torch.from_numpy(hot[:, 0].astype(np.int32)).to(dev)
             if not (self.packed is not None and self.shadow is not None

@@ -640,6 +640,17 @@ __global__ __launch_bounds__(XC_BLOCK) XC_SWEEP_OCC void bca_sweep_csr_kernel(Sw
             for (int c = 0; c < CH; ++c) differs = differs || (in_new[c] != in_old[c]);
             row_changed = __ballot(differs) != 0ull;
         }
+        // The prefetched row, its bounds and the next order entry are consumed HERE, before this row's stores:
+        // a first use at the rotation below would have to wait (vmcnt(0): the stores are conditional, hipcc
+        // cannot count past them) for every store and atomic of this row to be acknowledged.
+        const int s2u = uni(s2), e2u = uni(e2), row3u = uni(row3);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            int hs = (int)nxt.hot[c] | ((int)nxt.sel[c] << 8);
+            asm volatile("" : "+v"(nxt.idx[c]), "+v"(nxt.eta[c]), "+v"(nxt.sc[c]), "+v"(hs));
+            nxt.hot[c] = (uint8_t)(hs & 0xff);
+            nxt.sel[c] = (uint8_t)(hs >> 8);
+        }
         XC_STAMP(3); // top-k
         // The from-scratch recompute of the sweep boundary (block_coordinate.py:465-467:
         // tp / fp of the new prediction summed over ALL rows) is accumulated row by row
@@ -748,8 +759,8 @@ __global__ __launch_bounds__(XC_BLOCK) XC_SWEEP_OCC void bca_sweep_csr_kernel(Sw
         // ---- rotate the pipeline ----
         cur = nxt;
         row0 = row1; s0 = s1; e0 = e1;
-        row1 = row2; s1 = uni(s2); e1 = uni(e2);
-        row2 = uni(row3);
+        row1 = row2; s1 = s2u; e1 = e2u;
+        row2 = row3u;
 #ifdef XC_STAMPS
         // the rotation consumes the prefetched registers: wait for them here so the
         // stamp prices it
