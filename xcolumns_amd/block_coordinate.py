@@ -312,6 +312,8 @@ class BcaCsrEngine:
         # pipelined concurrent sweeps push their committed changes into the float64 records instead of rebuilding
         # `acc` (xc_bca_set_acc_delta; XCOLUMNS_BCA_ACC_DELTA=0 = from scratch in every sweep, as round 1 did)
         _lib.call("xc_bca_set_acc_delta", int(os.environ.get("XCOLUMNS_BCA_ACC_DELTA", "1") != "0"))
+        if os.environ.get("XCOLUMNS_BCA_HOT_UNPUBLISHED"):     # study knob: share of the rows whose hot-label deltas may wait
+            _lib.call("xc_bca_set_tuning", -1.0, float(os.environ["XCOLUMNS_BCA_HOT_UNPUBLISHED"]))
         # sharded rows: exchanges of the ranks' changes per sweep (1 = only the all-reduce of the
         # from-scratch statistics at the sweep boundary, the north-star scheme)
         # sweep), S > 1 = S - 1 more all-reduces of the float32 records inside the sweep, "auto" = several in
