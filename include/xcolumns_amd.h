@@ -338,9 +338,10 @@ int xc_bca_time_next_sweep(void *start, void *stop);
 int xc_bca_set_validation(int mode);
 
 /* Where a pipelined concurrent sweep leaves the statistics of its new prediction (block_coordinate.py:465-467
- * recomputes them from scratch at every boundary).  on = 1 (default): with the commit protocol on float32
- * shadow records, every committed change is pushed into the float64 records tpfp -- exact float64 sums of
- * float32 values, atomics for the rows that change only -- and the boundary reads them there.  on = 0: every
+ * recomputes them from scratch at every boundary).  on = 1 (default): with the commit protocol every committed
+ * change is pushed into the float64 records tpfp (next to the returning float32 atomics on the shadow records; the
+ * sweeps that gather tpfp itself commit there anyway) -- exact float64 sums of float32 values, atomics for the
+ * rows that change only -- and the boundary reads them there.  on = 0: every
  * row adds its k labels to `acc` (from scratch, as round 1 did: one 16-byte atomic per predicted label, 19 % of
  * a converged sweep at 1 M x 500 K).  xc_bca_plan_delta: does this plan's next pipelined sweep use the first form. */
 int xc_bca_set_acc_delta(int on);

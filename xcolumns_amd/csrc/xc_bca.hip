@@ -1466,7 +1466,8 @@ struct xc_bca_plan_s {
 // protocol on float32 shadow records, as the committed changes pushed into the float64 records -- exact float64
 // sums of float32 values either way, the second with atomics for the rows that CHANGE only.
 static int plan_delta(const xc_bca_plan_s *p) {
-    return xc::g_acc_delta && xc::g_validate == 2 && p->shadow != nullptr && p->acc != nullptr;
+    // (without a float32 shadow the commit protocol's returning atomics act on tpfp itself: nothing more to push)
+    return xc::g_acc_delta && xc::g_validate == 2 && p->acc != nullptr;
 }
 
 int xc_bca_plan_create(void **plan, int64_t n, int64_t m, int64_t n_total, const int32_t *indptr,
