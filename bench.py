@@ -375,7 +375,7 @@ def worker(args):
             eng.exchanges = max(1, args.exchanges)
         n_local = hi - lo
         policy = WavePolicy(n_local, fixed=args.waves if args.waves > 0 else None, world=world, k=K, m=m,
-                            row_nnz=R_NNZ, skewed=eng.skewed, parity=parity)   # as _bc_csr builds it
+                            row_nnz=R_NNZ, skewed=eng.skewed, parity=parity, sweeps=args.steps)   # as _bc_csr builds it
         # the reference's visiting order over the GLOBAL rows (np.random.default_rng(seed), cumulative
         # shuffles, block_coordinate.py:413-419), restricted to this rank's block
         rng = np.random.default_rng(ORDER_SEED)

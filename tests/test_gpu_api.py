@@ -219,6 +219,14 @@ def test_final_parity_policy(oref):
     assert dd.max() < 1e-5 and df[-1] < 1e-5 and df.max() < 5e-5
     with pytest.raises(ValueError):
         f(Y, k, bca_parity="sometimes")
+    # skewed labels: the default walks this matrix's first sweep sequentially (0.26 s); "final" takes the whole GPU from
+    # the first sweep on -- what that leaves behind (a few 1e-4) heals in the second sweep
+    Yz = make_csr(n, m, 50, seed=20240001, zipf=True, k=k)
+    _, moz = oref.predict_using_bc_with_0approx(Yz, metric, k, skip_tn=True, seed=13, max_iters=4, tolerance=-1.0)
+    _, mfz = f(Yz, k, seed=13, max_iters=4, tolerance=-1.0, return_meta=True, bca_diagnostics=True, bca_parity="final")
+    dz = np.abs(np.asarray(mfz["utilities"]) - np.asarray(moz["utilities"]))
+    print("final, Zipf", mfz["wavefronts"], dz)
+    assert mfz["wavefronts"][0] > 1000 and dz[1:].max() < 1e-5 and dz[0] < 2e-3
 
 
 def test_visiting_order_paths_agree():

@@ -84,7 +84,7 @@ def test_c3_amazon670k_shape_bca_vs_oracle(oref):
                                                        bca_parity="final", bca_diagnostics=True)
     df = np.abs(np.asarray(mf["utilities"]) - np.asarray(mo["utilities"]))
     print("C3 bca_parity=final, wavefronts", mf["wavefronts"], "|utility - oracle| per sweep:", df)
-    assert max(mf["wavefronts"]) > 1 and df.max() < 1e-4
+    assert max(mf["wavefronts"]) > 1000 and df.max() < 1e-4     # the whole GPU: the width does not move the difference here
     # bca_waves=1 is the reference's own sequence: identical prediction after one sweep
     Pe, me = predict_optimizing_macro_f1_score_using_bc(Y, k, seed=13, max_iters=1, tolerance=-1.0, return_meta=True, bca_waves=1)
     assert abs(me["utilities"][0] - mo["utilities"][0]) < 1e-12

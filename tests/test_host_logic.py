@@ -277,7 +277,9 @@ def test_wave_policy_rules():
         z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
         assert z.first_sequential and z.next(None) == 1 and z.next(100_000) == 750            # < 64 wavefronts: sequential
         zf = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True, parity="final")
-        assert not zf.first_sequential and zf.next(None) == int(6000 * 0.0616 * 30_000 / 200_000) == 55
+        assert not zf.first_sequential and zf.next(None) == 6000       # what a wide first sweep leaves heals in the second
+        zf1 = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True, parity="final", sweeps=1)
+        assert zf1.next(None) == int(6000 * 0.0616 * 30_000 / 200_000) == 55                # ... unless there is no second
         zl = bc.WavePolicy(1_000_000, m=500_000, row_nnz=50, k=5, skewed=True)
         assert not zl.first_sequential and zl.next(None) == int(0.05 * 500_000 * (10 / 12) ** 2.5 * 0.0616) == 976                                   # only the FIRST sweep is narrowed
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 6000
@@ -289,7 +291,8 @@ def test_wave_policy_rules():
         g = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5)                                   # ~1 predicted row per label
         assert g.sequential and g.next(None) == 1 and g.next(10) == 1
         gf = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5, parity="final")
-        assert not gf.sequential and 1 < gf.next(None) < 400 and gf.next(10) <= 2 * 4 * 0.05 * 670_000 * (150_000 * 5 / 670_000 / 12) ** 2.5 * 0.5 + 1
+        # "final" parity takes the whole GPU there: the width does not move the difference on such a shape (r02_c3_width.txt)
+        assert not gf.sequential and gf.next(None) == gf.cap and gf.next(10) == gf.cap
         with pytest.raises(ValueError):
             bc.WavePolicy(10, parity="sometimes")
     finally:

@@ -17,8 +17,8 @@ from xcolumns_amd.synthetic import make_csr  # noqa: E402
 oref.build()
 shape = os.environ.get("XC_SHAPE", "150000x670000")
 n, m = (int(x) for x in shape.split("x"))
-k, sweeps = 5, 4
-Y = make_csr(n, m, 50, seed=20240003, k=k)
+k, sweeps = 5, int(os.environ.get("XC_SWEEPS", "4"))
+Y = make_csr(n, m, 50, seed=20240003, k=k, zipf=os.environ.get("XC_ZIPF") == "1")
 Yd = DeviceCSR.from_scipy(Y)
 metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
 widths = [int(x) for x in sys.argv[1:]] or [8, 16, 32, 64, 128]

@@ -106,12 +106,13 @@ class WavePolicy:
     def __init__(self, n_order: int, fixed: Optional[int] = None, budget: Optional[float] = None,
                  world: int = 1, k: int = 5, first_changed: float = 0.5, m: Optional[int] = None,
                  row_nnz: float = 50.0, skewed: bool = False, parity: Optional[str] = None, scale: float = 1.0,
-                 first_sequential: bool = False):
+                 first_sequential: bool = False, sweeps: Optional[int] = None):
         """`n_order`: rows THIS rank visits per sweep; `world`: ranks sharing the rows (the changed-row
         count fed to :meth:`next` is the global one); `k`: labels per row; `first_changed`: expected share
         of rows the first sweep changes (about half from the top-k prediction, all of them from a random
         or foreign one); `m`: labels, `row_nnz`: mean stored entries per row, `skewed`: hot labels present
-        (first sweep narrower); `parity`: "per_sweep" | "final"; `scale`: extra factor on the width.
+        (first sweep narrower); `parity`: "per_sweep" | "final"; `scale`: extra factor on the width; `sweeps`:
+        the most sweeps the run may do (max_iters), if known.
         `budget` (or XCOLUMNS_BCA_STALE_BUDGET) selects the round-1 rule instead: W = budget * n^2 / changed."""
         self.first_changed = float(first_changed)
         # the first sweep of a random / foreign start changes every label of every row: it runs as the
@@ -157,7 +158,15 @@ class WavePolicy:
                 # cannot be tracked to 1e-5 by anything but its own sequence: these shapes run the sequential sweep
                 # (exact; 0.25 s per sweep at C3) unless the caller asks for bca_parity="final" or a width.
                 self.fixed = 1
-            if per_label < 4.0:
+            full_width = False
+            if per_label < 2.0 and self.parity == "final" and not self.fixed:
+                # ... and with "final" parity they take the whole GPU: with the commit protocol 8, 64, 1024 and 8192
+                # wavefronts all end a sweep 1e-7 .. 1.1e-5 from the sequential trajectory (three visiting orders each,
+                # profiles/r02_c3_width.txt) -- what moves the utility there is the order in which conflicting rows
+                # happen to commit, not how many rows are in flight, so a narrow sweep buys nothing
+                full_width = True
+                self.num = float(self.n) * float(self.n)
+            if per_label < 4.0 and not full_width:
                 width *= 0.5     # three runs at 71 / 39 / 110 wavefronts ended sweep 3 at 2.9e-6, 8.7e-6, 9.0e-6: too close
                 self.num = width * self.n / 2.0
                 self.width_cap = max(1, int(2.0 * width))
@@ -165,6 +174,11 @@ class WavePolicy:
             # a single decision that falls the other way moves such a label's F1 by ~0.3, i.e. the utility by
             # 0.3 / m: on a 30 K-label space three of them are the whole 1e-5
             self.first_factor = _SKEWED_FIRST_SWEEP * min(1.0, float(m) / 200000.0) if skewed else 1.0
+            if skewed and self.parity == "final" and (sweeps is None or int(sweeps) >= 2):
+                # what a wide first sweep leaves behind on skewed labels heals in the next one: 100 K x 30 K Zipf at 8192
+                # wavefronts 1.9-3.6e-4 after sweep 1, 2.9-4.3e-6 after sweep 2, <= 3e-7 from sweep 3 on (three visiting
+                # orders, profiles/r02_c3_width.txt); 1 M x 500 K: 3.2e-5, then 3.8e-7.  "final" promises the last sweep.
+                self.first_factor = 1.0
             # ... and when that leaves fewer than 64 wavefronts the first sweep runs as the reference's sequential
             # sweep: on 100 K x 30 K Zipf ONE tail label that is predicted by a different row is 1-2e-5 of utility,
             # and 22 .. 250 wavefronts all measure 0.5-2e-5 in sweep 1 (six runs each, profiles/r02_c2_zipf_width.txt)
@@ -1144,7 +1158,7 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
     parity = default_parity() if bca_parity is None else bca_parity
     policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if calm else 1.0,
                         m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.skewed,
-                        parity=parity, scale=1.0 if calm else 0.25,
+                        parity=parity, scale=1.0 if calm else 0.25, sweeps=max_iters,
                         first_sequential=not calm and not greedy and parity == "per_sweep" and normalize_first)
     try:
         run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
