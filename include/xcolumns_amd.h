@@ -175,6 +175,21 @@ int xc_confusion_csr_bucketed(int64_t n, int64_t m, const int32_t *t_indptr,
                               const void *p_data, int dtype, int64_t nnz_true, int64_t nnz_pred,
                               double *tp, double *fp, double *fn, void *workspace, void *stream);
 
+/* The same statistics with atomics for the PREDICTED entries only, given the column sums of y_true:
+ *   fn[j] = colsum_t[j] - sum over the entries of y_true that meet a predicted one of [t - (T)(t (1 - p))].
+ * The caller puts colsum_t (float64 sums of y_true's columns; it depends on y_true alone and can be kept) into fn and
+ * zeros into tp, fp; nnz(y_pred) + 2 matches atomics instead of nnz(y_pred) + nnz(y_true).  Both matrices need rows of
+ * strictly ascending column ids (numba_csr_functions.py:121): y_true's are the caller's to check
+ * (xc_csr_rows_ascending: *flag |= 1 if some row is not), a row of y_pred that is not -- the top-k padding of a
+ * short row -- sets *flag |= 1 and the results are to be discarded (xc_confusion_csr reproduces that case). */
+int xc_csr_rows_ascending(int64_t n, const int32_t *indptr, const int32_t *indices, int32_t *flag,
+                          void *stream);
+int xc_confusion_csr_pred_side(int64_t n, int64_t m, const int32_t *t_indptr,
+                               const int32_t *t_indices, const void *t_data,
+                               const int32_t *p_indptr, const int32_t *p_indices,
+                               const void *p_data, int dtype, double *tp, double *fp, double *fn,
+                               int32_t *flag, void *stream);
+
 /* dense branch (confusion_matrix.py:160-166, :187-202): products in `dtype`,
  * column sums in float64.  y_true, y_pred: n x m contiguous. */
 int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_pred,

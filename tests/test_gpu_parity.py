@@ -234,6 +234,48 @@ def test_confusion_bucketed_vs_oracle_large(oref, dtype, monkeypatch):
     assert np.allclose(got["0"], got["1"], rtol=1e-13, atol=1e-13)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_confusion_prediction_side_vs_oracle(oref, dtype, monkeypatch):
+    """Large inputs with well-formed rows take xc_confusion_csr_pred_side (atomics for the predicted entries only, fn
+    from the cached column sums of y_true): same statistics as the oracle and as the general kernel, first call and
+    cached; a prediction with a padded short row falls back to the general kernel."""
+    from xcolumns_amd import DeviceCSR
+    from xcolumns_amd.confusion_matrix import calculate_confusion_matrix
+    from xcolumns_amd.weighted_prediction import predict_top_k
+    rng = np.random.default_rng(12)
+    n, m, k = 200_000, 150_000, 5
+    lens = rng.integers(k, 30, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = rng.integers(0, m, size=int(indptr[-1])).astype(np.int32)
+    Y = csr_matrix((rng.random(indptr[-1]).astype(dtype), cols, indptr), shape=(n, m))
+    Y.sum_duplicates()
+    Y.sort_indices()
+    Y = Y[np.diff(Y.indptr) >= k]                      # duplicates may have shortened a row below k
+    n = Y.shape[0]
+    T = Y.copy()
+    T.data = (rng.random(T.nnz) < 0.4).astype(dtype) * T.data     # y_true: some entries kept, some explicit zeros
+    Td, Yd = DeviceCSR.from_scipy(T), DeviceCSR.from_scipy(Y)
+    Pd = predict_top_k(Yd, k, keep_scores=True)
+    P = Pd.to_scipy()
+    exp = np.stack(oref.calculate_confusion_matrix(T, P, skip_tn=True)[:3])
+    for call in range(2):                               # second call: column sums and row check come from the cache
+        C = calculate_confusion_matrix(Td, Pd, skip_tn=True, dtype=torch.float64)
+        got = np.stack([C.tp.cpu().numpy(), C.fp.cpu().numpy(), C.fn.cpu().numpy()])
+        assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), call
+        assert "_colsum64" in Td.__dict__ and Td.rows_ascending()
+    monkeypatch.setenv("XCOLUMNS_CONFUSION_PRED_SIDE", "0")
+    C = calculate_confusion_matrix(Td, Pd, skip_tn=True, dtype=torch.float64)
+    assert np.allclose(np.stack([C.tp.cpu().numpy(), C.fp.cpu().numpy(), C.fn.cpu().numpy()]), got, rtol=1e-12, atol=1e-12)
+    monkeypatch.delenv("XCOLUMNS_CONFUSION_PRED_SIDE")
+    # a padded row in the prediction (k + 1 labels from rows that hold only k): the fast kernel flags it, the general one answers
+    short = int(np.argmin(np.diff(Y.indptr)))
+    if Y.indptr[short + 1] - Y.indptr[short] == k:
+        P6 = predict_top_k(Y, k + 1)
+        exp6 = np.stack(oref.calculate_confusion_matrix(T, P6, skip_tn=True)[:3])
+        C6 = calculate_confusion_matrix(Td, DeviceCSR.from_scipy(P6), skip_tn=True, dtype=torch.float64)
+        assert np.allclose(np.stack([C6.tp.cpu().numpy(), C6.fp.cpu().numpy(), C6.fn.cpu().numpy()]), exp6, rtol=1e-12, atol=1e-12)
+
+
 # ---------------------------------------------------------------------------
 # BCA, exact sequential mode (one wavefront walks the order): must reproduce the
 # reference's trajectory

@@ -52,5 +52,18 @@ for name, n, m, binary in (("ns_1Mx500K, y_true = y_proba (50 entries/row)", 1_0
     rel = float(((a - b).abs() / a.abs().clamp_min(1.0)).max())
     print("  atomic   ms:", " ".join("%.3f" % x for x in ms_a))
     print("  bucketed ms:", " ".join("%.3f" % x for x in ms_b), f"   max relative difference {rel:.2e}", flush=True)
+    os.environ.pop("XCOLUMNS_CONFUSION_BUCKETED")
+    t.forget_cached()
+    ms_c = []
+    for _ in range(6):      # the first call also sums the columns of y_true and checks its rows; the others find them cached
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        c = confusion_csr_device(t, pred)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_c.append(e0.elapsed_time(e1))
+    rel = float(((a - c).abs() / a.abs().clamp_min(1.0)).max())
+    print("  prediction side (default) ms:", " ".join("%.3f" % x for x in ms_c), f"   max relative difference {rel:.2e}", flush=True)
     del t, p, pred, a, b
     torch.cuda.empty_cache()

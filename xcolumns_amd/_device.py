@@ -128,6 +128,44 @@ class DeviceCSR:
     def ndim(self) -> int:
         return 2
 
+    # -- derived quantities that depend on this matrix alone, computed once (a DeviceCSR is a read-only view: whoever
+    # rewrites its tensors in place calls forget_cached()) --------------------------------------------------------
+    def forget_cached(self) -> None:
+        self.__dict__.pop("_colsum64", None)
+        self.__dict__.pop("_ascending", None)
+
+    def column_sums(self) -> torch.Tensor:
+        """float64[m] sums of the stored values per column (bucketed counting sort + LDS sums for float32 values,
+        xc_scatter_sum_f32; one float64 atomic per entry otherwise)."""
+        cs = self.__dict__.get("_colsum64")
+        if cs is None:
+            import ctypes
+            from . import _lib
+            cs = torch.zeros(self.m, dtype=torch.float64, device=self.data.device)
+            if self.nnz > 0:
+                if self.data.dtype == torch.float32 and self.nnz >= (1 << 18) and self.m <= 16384 * 2048:
+                    nbytes = ctypes.c_int64(0)
+                    _lib.call("xc_scatter_sum_workspace_bytes", self.nnz, self.m, ctypes.byref(nbytes))
+                    ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.data.device)
+                    _lib.call("xc_scatter_sum_f32", self.nnz, ptr(self.indices), ptr(self.data), self.m, 0, ptr(cs), ptr(ws),
+                              stream())
+                    ws.record_stream(torch.cuda.current_stream())
+                else:
+                    _lib.call("xc_bca_colsum_csr", self.nnz, ptr(self.indices), ptr(self.data), self.code, ptr(cs), stream())
+            self.__dict__["_colsum64"] = cs
+        return cs
+
+    def rows_ascending(self) -> bool:
+        """Strictly ascending column ids in every row (what the reference requires of a csr_matrix)."""
+        asc = self.__dict__.get("_ascending")
+        if asc is None:
+            from . import _lib
+            flag = torch.zeros(1, dtype=torch.int32, device=self.data.device)
+            _lib.call("xc_csr_rows_ascending", self.n, ptr(self.indptr), ptr(self.indices), ptr(flag), stream())
+            asc = int(flag.item()) == 0
+            self.__dict__["_ascending"] = asc
+        return asc
+
     @staticmethod
     def from_parts(indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor, shape, device=None,
                    check: bool = True) -> "DeviceCSR":

@@ -321,6 +321,64 @@ static ConfPlan make_conf_plan(int64_t n, int64_t m) {
 
 static int64_t conf_items_bound(int64_t nnz_true, int64_t nnz_pred) { return 2 * nnz_pred + nnz_true; }
 
+// ---- prediction-side form ---------------------------------------------------------------
+// fn[j] = sum_i t_ij (1 - p_ij) runs over the stored entries of y_true -- 50 M atomics at 1 M x 500 K, of which
+// only the entries that MEET a predicted one (at most nnz(y_pred)) differ from the plain column sum of y_true:
+//   fn[j] = colsum_t[j] - sum over matched (i, j) of [ t - (T)(t (1 - p)) ]
+// (exact differences of two T values in float64).  With colsum_t known -- it depends on y_true alone, the host
+// caches it per matrix -- a thread per row walks the row's PREDICTED entries only, finds each in the row of y_true by
+// binary search and issues tp / fp / the fn correction: nnz(y_pred) + 2 * matches atomics instead of
+// nnz(y_pred) + nnz(y_true).  Requires rows of both matrices with strictly ascending column ids (what the reference
+// requires of a csr_matrix, numba_csr_functions.py:121); a row of y_pred that breaks this -- the top-k padding of a
+// short row -- raises `flag` and the host falls back to the general kernel.
+template <typename T>
+__global__ __launch_bounds__(XC_BLOCK) void confusion_pred_side_kernel(int64_t n, const int32_t *t_indptr,
+                                                                       const int32_t *t_indices, const T *t_data,
+                                                                       const int32_t *p_indptr, const int32_t *p_indices,
+                                                                       const T *p_data, double *tp, double *fp, double *fn,
+                                                                       int *flag) {
+    for (int64_t row = (int64_t)blockIdx.x * XC_BLOCK + threadIdx.x; row < n; row += (int64_t)gridDim.x * XC_BLOCK) {
+        const int ts = t_indptr[row], te = t_indptr[row + 1];
+        const int ps = p_indptr[row], pe = p_indptr[row + 1];
+        int prev = -1;
+        for (int q = ps; q < pe; ++q) {
+            const int col = p_indices[q];
+            if (col <= prev) { // not strictly ascending: the general kernel's repeat / merge rules apply
+                atomicOr(flag, 1);
+                break;
+            }
+            prev = col;
+            const T pv = p_data[q];
+            const int t = lower_bound_col(t_indices, ts, te, col);
+            if (t < te && t_indices[t] == col) {
+                const T tv = t_data[t];
+                // (zeros are not sent: a 0/1 y_true makes every matched fp term one, an explicit zero in it every tp term)
+                const double a = (double)(T)(pv * tv);                                        // :133
+                const double b = (double)(T)((double)pv * (1.0 - (double)tv));                // :197, :206
+                const double corr = (double)tv - (double)(T)((double)tv * (1.0 - (double)pv)); // what this entry no longer adds
+                if (a != 0.0) atomic_add_f64(tp + col, a);
+                if (b != 0.0) atomic_add_f64(fp + col, b);
+                if (corr != 0.0) atomic_add_f64(fn + col, -corr);
+            } else {
+                atomic_add_f64(fp + col, (double)pv); // :200-203
+            }
+        }
+    }
+}
+
+// strictly ascending column ids in every row?  A 16-lane group per row; flag |= 1 otherwise.
+__global__ __launch_bounds__(XC_BLOCK) void csr_rows_ascending_kernel(int64_t n, const int32_t *indptr, const int32_t *indices,
+                                                                      int *flag) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t groups = (int64_t)gridDim.x * (XC_BLOCK / 16);
+    bool bad = false;
+    for (int64_t row = (int64_t)blockIdx.x * (XC_BLOCK / 16) + (threadIdx.x >> 4); row < n; row += groups) {
+        const int s = indptr[row], e = indptr[row + 1];
+        for (int q = s + 1 + l16; q < e; q += 16) bad = bad || (indices[q] <= indices[q - 1]);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
 // Dense: a workgroup owns a strip of XC_BLOCK columns x ROWS_PER_BLOCK rows,
 // each thread sums its column over the strip's rows in row order (coalesced
 // row-major reads) and pushes one atomic per statistic.
@@ -451,6 +509,39 @@ int xc_confusion_csr_bucketed(int64_t n, int64_t m, const int32_t *t_indptr, con
         xc::launch_confusion_bucketed<double>(P, t_indptr, t_indices, t_data, p_indptr, p_indices, p_data, tp, fp, fn,
                                           static_cast<char *>(workspace), st);
     XC_CHECK_LAUNCH("confusion bucket kernels");
+    return XC_OK;
+}
+
+int xc_csr_rows_ascending(int64_t n, const int32_t *indptr, const int32_t *indices, int32_t *flag, void *stream) {
+    if (n < 0 || !indptr || !flag) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_csr_rows_ascending: bad argument");
+    if (n == 0) return XC_OK;
+    int64_t blocks = (n + (XC_BLOCK / 16) - 1) / (XC_BLOCK / 16);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(xc::csr_rows_ascending_kernel, dim3((unsigned)blocks), dim3(XC_BLOCK), 0, xc::as_stream(stream), n, indptr,
+                       indices, flag);
+    XC_CHECK_LAUNCH("csr_rows_ascending_kernel");
+    return XC_OK;
+}
+
+int xc_confusion_csr_pred_side(int64_t n, int64_t m, const int32_t *t_indptr, const int32_t *t_indices, const void *t_data,
+                               const int32_t *p_indptr, const int32_t *p_indices, const void *p_data, int dtype, double *tp,
+                               double *fp, double *fn, int32_t *flag, void *stream) {
+    if (n < 0 || m < 1 || !t_indptr || !p_indptr || !tp || !fp || !fn || !flag)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_pred_side: NULL pointer or negative size");
+    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_pred_side: unknown dtype %d", dtype);
+    if (n == 0) return XC_OK;
+    int64_t blocks = (n + XC_BLOCK - 1) / XC_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = xc::as_stream(stream);
+    if (dtype == XC_F32)
+        hipLaunchKernelGGL((xc::confusion_pred_side_kernel<float>), dim3((unsigned)blocks), dim3(XC_BLOCK), 0, st, n, t_indptr,
+                           t_indices, static_cast<const float *>(t_data), p_indptr, p_indices, static_cast<const float *>(p_data),
+                           tp, fp, fn, flag);
+    else
+        hipLaunchKernelGGL((xc::confusion_pred_side_kernel<double>), dim3((unsigned)blocks), dim3(XC_BLOCK), 0, st, n, t_indptr,
+                           t_indices, static_cast<const double *>(t_data), p_indptr, p_indices, static_cast<const double *>(p_data),
+                           tp, fp, fn, flag);
+    XC_CHECK_LAUNCH("confusion_pred_side_kernel");
     return XC_OK;
 }
 
