@@ -198,6 +198,18 @@ def test_boundary_statistics_are_those_of_the_prediction(oref, zipf, delta, monk
     print("acc_delta", delta, "zipf", zipf, "|reported - from scratch|", abs(u - mg["utilities"][-1]), "per sweep vs oracle", d)
     assert abs(u - mg["utilities"][-1]) < 1e-11
     assert d.max() < 1e-5
+    if not zipf:
+        # float64 scores (no packed stream; the reference's own dtype for its statistics), longer budget, shorter run
+        Y64 = Y[:40_000].astype(np.float64)
+        n64, k64 = Y64.shape[0], 8
+        metric64 = oref.make_metric(oref.FBETA, k=float(k64), m=float(m))
+        _, mo64 = oref.predict_using_bc_with_0approx(Y64, metric64, k64, skip_tn=True, seed=3, max_iters=4, tolerance=-1.0)
+        P64, mg64 = f(Y64, k64, seed=3, max_iters=4, tolerance=-1.0, return_meta=True)
+        tp, fp, fn, tn = oref.calculate_confusion_matrix(Y64, P64, skip_tn=True)
+        u64 = oref.calculate_utility(metric64, "mean", tp / n64, fp / n64, fn / n64, tn / n64)
+        d64 = np.abs(np.asarray(mg64["utilities"]) - np.asarray(mo64["utilities"]))
+        print("  float64 scores, k = 8: |reported - from scratch|", abs(u64 - mg64["utilities"][-1]), "per sweep vs oracle", d64)
+        assert abs(u64 - mg64["utilities"][-1]) < 1e-11 and d64.max() < 1e-5
 
 
 def test_final_parity_policy(oref):
