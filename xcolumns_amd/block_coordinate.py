@@ -1122,45 +1122,48 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
                 f"every row of a sparse y_proba must store at least k={k} entries on the GPU path "
                 f"(shortest row has {int(row_nnz.min())})")
     dev = D.require_gpu()
-    csr = D.as_device_csr(y_proba, dev)
-    eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
-                       deterministic=bca_deterministic)
-
-    log_info("  Initializing initial prediction ...", verbose)
-    greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"
-    init_idx = _initial_csr_indices(y_proba, init_y_pred, k, seed)
-    if init_idx is None:
-        eng.init_top()
-    else:
-        if isinstance(init_idx, torch.Tensor):
-            init_dev = init_idx.to(device=dev, dtype=torch.int32).clone()
-        else:
-            init_dev = torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)).to(dev)
-        D.check_column_ids(init_dev, m, "init_y_pred")
-        eng.init_indices(init_dev)
-
+    # the host starts walking the visiting orders NOW: the first ones are ready by the time the matrix is uploaded,
+    # packed and its initial prediction made (the walk is what bounds a call on a resident matrix: ~1.3 ms per
+    # 1 M-row order behind a 0.5 ms sweep)
     orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
-    if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
-        # Macro precision tp / (tp + fp) jumps when a rarely predicted label gains or loses a row: rows in
-        # flight that pick the same attractive label all take it, and the run ends 1e-4 .. 1e-3 BELOW the
-        # sequential one even with two wavefronts (tests/studies/fuzz_concurrent.py).  Parity first: the
-        # reference's sequential sweep unless the caller sets bca_waves.
-        log_info("  macro precision: using the sequential sweep (bca_waves=1); set bca_waves to trade parity for speed",
-                 verbose)
-        bca_waves = 1
-    # a random / foreign / greedy start changes every row in sweep 1 and keeps many rows moving for several
-    # sweeps (measured 5e-5 .. 1.2e-4 at the top-k width): half the budget for the whole run
-    # a random / foreign / greedy start -- and a minimisation from the top-k start, the worst point for it --
-    # changes every row in sweep 1 and keeps many rows moving for several sweeps (measured 1.0-1.1e-5 in sweep 1
-    # at half the top-k width): a quarter of the width for the whole run
-    normalize_first = n_u >= n_rows
-    calm = init_idx is None and maximize   # a minimisation starts from its worst point: every row changes
-    parity = default_parity() if bca_parity is None else bca_parity
-    policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if calm else 1.0,
-                        m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.skewed,
-                        parity=parity, scale=1.0 if calm else 0.25, sweeps=max_iters,
-                        first_sequential=not calm and not greedy and parity == "per_sweep" and normalize_first)
     try:
+        csr = D.as_device_csr(y_proba, dev)
+        eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
+                           deterministic=bca_deterministic)
+
+        log_info("  Initializing initial prediction ...", verbose)
+        greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"
+        init_idx = _initial_csr_indices(y_proba, init_y_pred, k, seed)
+        if init_idx is None:
+            eng.init_top()
+        else:
+            if isinstance(init_idx, torch.Tensor):
+                init_dev = init_idx.to(device=dev, dtype=torch.int32).clone()
+            else:
+                init_dev = torch.from_numpy(np.ascontiguousarray(init_idx, dtype=np.int32)).to(dev)
+            D.check_column_ids(init_dev, m, "init_y_pred")
+            eng.init_indices(init_dev)
+
+        if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
+            # Macro precision tp / (tp + fp) jumps when a rarely predicted label gains or loses a row: rows in
+            # flight that pick the same attractive label all take it, and the run ends 1e-4 .. 1e-3 BELOW the
+            # sequential one even with two wavefronts (tests/studies/fuzz_concurrent.py).  Parity first: the
+            # reference's sequential sweep unless the caller sets bca_waves.
+            log_info("  macro precision: using the sequential sweep (bca_waves=1); set bca_waves to trade parity for speed",
+                     verbose)
+            bca_waves = 1
+        # a random / foreign / greedy start changes every row in sweep 1 and keeps many rows moving for several
+        # sweeps (measured 5e-5 .. 1.2e-4 at the top-k width): half the budget for the whole run
+        # a random / foreign / greedy start -- and a minimisation from the top-k start, the worst point for it --
+        # changes every row in sweep 1 and keeps many rows moving for several sweeps (measured 1.0-1.1e-5 in sweep 1
+        # at half the top-k width): a quarter of the width for the whole run
+        normalize_first = n_u >= n_rows
+        calm = init_idx is None and maximize   # a minimisation starts from its worst point: every row changes
+        parity = default_parity() if bca_parity is None else bca_parity
+        policy = WavePolicy(n_u, fixed=bca_waves, k=k, first_changed=0.5 if calm else 1.0,
+                            m=m, row_nnz=csr.nnz / max(1, n_rows), skewed=eng.skewed,
+                            parity=parity, scale=1.0 if calm else 0.25, sweeps=max_iters,
+                            first_sequential=not calm and not greedy and parity == "per_sweep" and normalize_first)
         run_bca_sweeps(eng, orders.next, n_u, n_u, m, metric_aggregation, maximize, tolerance, max_iters, greedy,
                        policy, verbose, meta)
     finally:
