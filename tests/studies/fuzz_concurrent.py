@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the CONCURRENT default (GPU box): medium random problems through
 predict_using_bc_with_0approx against the sequential oracle; prints the worst per-sweep and the final
-utility difference of every case and flags those over the test suite's bars (5e-5 / 1e-5).
+utility difference of every case and flags those over the bar (1e-5 at EVERY sweep, round 2).
 
     python tests/studies/fuzz_concurrent.py [cases] [first_seed]
 """
@@ -38,7 +38,7 @@ for seed in range(first, first + cases):
     _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, **kw)
     _, mg = bc.predict_using_bc_with_0approx(Y, getattr(bc, name), k, return_meta=True, bca_diagnostics=True, **kw)
     d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
-    flag = "OVER" if (d.max() > 5e-5 or d[-1] > 1e-5) else "ok"
+    flag = "OVER" if d.max() > 1e-5 else "ok"
     over += flag == "OVER"
     print(f"{flag:4s} seed={seed} n={n} m={m} r={r} k={k} zipf={zipf} {np.dtype(dtype).name} {name[7:-15]} init={init} "
           f"W={mg['wavefronts'][:3]} max {d.max():.1e} final {d[-1]:.1e}", flush=True)
