@@ -118,6 +118,7 @@ class WavePolicy:
         # the first sweep of a random / foreign start changes every label of every row: it runs as the
         # reference's sequential sweep (exact) unless the caller asked for "final" parity or a fixed width
         self.first_sequential = bool(first_sequential)
+        self.sequential_below = 0      # a sweep the rule leaves fewer wavefronts than this runs sequentially (skewed labels)
         self.world = max(1, int(world))
         env = os.environ.get("XCOLUMNS_BCA_WAVES")
         self.fixed = int(fixed) if fixed else (int(env) if env else None)
@@ -142,8 +143,12 @@ class WavePolicy:
             # and the bar is absolute: one label's F1 weighs 1 / m in the utility, so on a small label space a
             # handful of decisions that fall the other way are already 1e-5 (20 K x 5 K: 1.0-1.7e-5 at 0.064 m
             # rows in flight, 4e-6 at half of that)
-            small_m = min(1.0, float(m) / 30000.0) ** 0.5
-            width = (_BETA * float(m) * (50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
+            # (linear below 30 K labels since the fuzz of round 2: 31 K x 7 K, k = 3 measured 1.2-1.5e-5 at 358 wavefronts
+            # and 4-7e-6 at 225 with the square root; tools/r02_fuzz_case.py 1042)
+            small_m = min(1.0, float(m) / 30000.0)
+            # (longer rows than 50 entries narrow the sweep -- more candidates per row meet a row in flight; shorter ones
+            # do not widen it: 10 entries per row at 5x measured 2.6e-5 in sweep 1 on 31 K x 7 K)
+            width = (_BETA * float(m) * min(1.0, 50.0 / max(1.0, float(row_nnz))) * k_scale * float(scale)
                      * min(1.0, per_label / 12.0) ** 2.5 * small_m)
             if self.parity == "final":
                 width *= _FINAL_PARITY_FACTOR
@@ -157,6 +162,16 @@ class WavePolicy:
                 # moves by 1.2-3.8e-5 (standard deviation) there when only its visiting order changes, so its trajectory
                 # cannot be tracked to 1e-5 by anything but its own sequence: these shapes run the sequential sweep
                 # (exact; 0.25 s per sweep at C3) unless the caller asks for bca_parity="final" or a width.
+                self.fixed = 1
+            if per_label < 4.0 and float(m) < 30000.0 and self.parity == "per_sweep" and not self.fixed:
+                # few predicted rows per label on a SMALL label space: one decision that falls the other way is the
+                # whole bar (1 / m per label), and 17-35 wavefronts still measured 1.5e-5 on 37 K x 20 K, k = 2
+                # (per_label 3.7; the fuzz of round 2, seed 1065) -- a sequential sweep of such a matrix takes 60 ms
+                self.fixed = 1
+            if 2.0 * max(1, int(k)) > float(row_nnz) and self.parity == "per_sweep" and not self.fixed:
+                # a budget of more than half of a row's candidates (35 K x 14 K, 12 entries per row, k = 7: the fuzz of
+                # round 2) is another shape whose trajectory nothing but its own sequence tracks: TWO wavefronts already
+                # sit 1-5e-5 from it, and nearly half of the rows still change in the second sweep
                 self.fixed = 1
             full_width = False
             if per_label < 2.0 and self.parity == "final" and not self.fixed:
@@ -186,6 +201,10 @@ class WavePolicy:
             if (skewed and self.parity == "per_sweep" and not self.fixed
                     and self.num * self.first_factor / (self.n * self.first_changed) < 64.0):
                 self.first_sequential = True
+            # the same holds for a LATER sweep that still changes so many rows that the rule leaves it fewer than 64
+            # wavefronts (the sweep after a greedy or random start on 22 K x 7 K Zipf: 54 wavefronts, 0.8-1.3e-5)
+            if skewed and self.parity == "per_sweep" and not self.fixed:
+                self.sequential_below = 64
         self.budget = self.num / (float(self.n) * float(self.n))   # the same rule as a share of n (diagnostics)
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
@@ -208,6 +227,8 @@ class WavePolicy:
             want = int(self.num * self.first_factor / (self.n * self.first_changed))
         else:
             want = int(self.num / max(1.0, changed_prev / self.world))
+            if want < self.sequential_below:
+                return 1
         return int(max(1, min(self.cap, self.n, max(_MIN_WAVES, want))))
 
     def device_params(self):
@@ -984,7 +1005,7 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
     div = m if metric_aggregation == "mean" else 1
     for j in range(1, max_iters + 1):
         if (not greedy and not getattr(policy, "sequential", True) and hasattr(eng, "can_pipeline")
-                and eng.can_pipeline(n_order) and not (j == 1 and getattr(policy, "first_sequential", False))):
+                and eng.can_pipeline(n_order) and policy.next(changed_prev) > 1):
             # every remaining sweep is a full concurrent one: hand the stopping rule to the GPU
             if new_utility_sum is None:
                 if j == 1:
