@@ -163,10 +163,11 @@ class WavePolicy:
                 # cannot be tracked to 1e-5 by anything but its own sequence: these shapes run the sequential sweep
                 # (exact; 0.25 s per sweep at C3) unless the caller asks for bca_parity="final" or a width.
                 self.fixed = 1
-            if per_label < 4.0 and float(m) < 30000.0 and self.parity == "per_sweep" and not self.fixed:
+            if per_label < 8.0 and float(m) < 30000.0 and self.parity == "per_sweep" and not self.fixed:
                 # few predicted rows per label on a SMALL label space: one decision that falls the other way is the
                 # whole bar (1 / m per label), and 17-35 wavefronts still measured 1.5e-5 on 37 K x 20 K, k = 2
-                # (per_label 3.7; the fuzz of round 2, seed 1065) -- a sequential sweep of such a matrix takes 60 ms
+                # (3.7 rows per label; the fuzz of round 2, seed 1065), 11-27 wavefronts 1.3e-5 on 22 K x 10.5 K, k = 2
+                # (4.1; seed 3059) -- a sequential sweep of such a matrix takes 40-60 ms
                 self.fixed = 1
             if 2.0 * max(1, int(k)) > float(row_nnz) and self.parity == "per_sweep" and not self.fixed:
                 # a budget of more than half of a row's candidates (35 K x 14 K, 12 entries per row, k = 7: the fuzz of
