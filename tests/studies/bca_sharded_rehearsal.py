@@ -2,7 +2,7 @@
 one all-reduce of acc per sweep).  Checks: same utilities and stopping decision on both ranks, the last
 utility is the utility of the assembled prediction, and the trace stays near the sequential oracle's
 (other ranks' updates are invisible within a sweep: DESIGN.md section 7).
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 tools/bca_sharded_rehearsal.py"""
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 tests/studies/bca_sharded_rehearsal.py"""
 import os, sys
 import numpy as np
 import torch

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Round-2 study (GPU box): one case of tests/studies/fuzz_concurrent.py by its seed, per-sweep differences, a few runs,
-optionally at fixed widths:  python tools/r02_fuzz_case.py SEED [W ...]"""
+optionally at fixed widths:  python tests/studies/fuzz_case.py SEED [W ...]"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref as oref  # noqa: E402
 import xcolumns_amd.block_coordinate as bc  # noqa: E402
 from xcolumns_amd.synthetic import make_csr  # noqa: E402

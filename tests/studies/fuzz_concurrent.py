@@ -23,17 +23,24 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 over = 0
 for seed in range(first, first + cases):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(3000, 40000))
-    m = int(rng.integers(200, 20000))
-    r = int(rng.integers(10, 60))
-    k = int(rng.integers(1, 9))
+    if os.environ.get("XC_FUZZ_SCALE") == "medium":     # between BASELINE configs[1] and the north-star size
+        n = int(rng.integers(50_000, 250_000))
+        m = int(rng.integers(20_000, 400_000))
+        r = int(rng.integers(20, 110))
+        k = int(rng.integers(1, 9))
+    else:
+        n = int(rng.integers(3000, 40000))
+        m = int(rng.integers(200, 20000))
+        r = int(rng.integers(10, 60))
+        k = int(rng.integers(1, 9))
     zipf = bool(rng.random() < 0.4)
     dtype = np.float32 if rng.random() < 0.7 else np.float64
     name, base, skip_tn = METRICS[int(rng.integers(len(METRICS)))]
     init = str(rng.choice(["top", "top", "random", "greedy"]))
     Y = make_csr(n, max(m, r + 1), r, seed=seed, zipf=zipf, k=k, dtype=dtype)
     m = Y.shape[1]
-    kw = dict(seed=int(rng.integers(100)), max_iters=6, tolerance=-1.0, skip_tn=skip_tn, init_y_pred=init)
+    kw = dict(seed=int(rng.integers(100)), max_iters=4 if os.environ.get("XC_FUZZ_SCALE") == "medium" else 6, tolerance=-1.0,
+              skip_tn=skip_tn, init_y_pred=init)
     metric = oref.make_metric(base, k=float(k), m=float(m))
     _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, **kw)
     _, mg = bc.predict_using_bc_with_0approx(Y, getattr(bc, name), k, return_meta=True, bca_diagnostics=True, **kw)

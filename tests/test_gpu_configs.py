@@ -138,7 +138,8 @@ def _two_ranks(script, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", script)]
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "studies", script) if os.path.exists(os.path.join(ROOT, "tests", "studies", script))
+           else os.path.join(ROOT, "tools", script)]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     return out.stdout
@@ -147,7 +148,7 @@ def _two_ranks(script, env_extra, timeout=900):
 def test_c4_wiki500k_shape_bca_two_row_shards(oref):
     """configs[3] is "instance-sharded": the 780 K rows split over two ranks (one GPU, gloo; the real GPU engine,
     device-side loop, default exchange schedule).  Both ranks report the same trace, the last utility is the
-    utility of the assembled prediction (asserted inside tools/bca_sharded_rehearsal.py against the oracle's
+    utility of the assembled prediction (asserted inside tests/studies/bca_sharded_rehearsal.py against the oracle's
     confusion matrix), and the run ends within 1e-5 of the unsharded GPU run after the same 6 sweeps."""
     from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc
     from xcolumns_amd.synthetic import make_csr_rows

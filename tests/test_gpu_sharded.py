@@ -25,7 +25,8 @@ def _run(script, env_extra=None):
     env = dict(os.environ)
     env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", script)]
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "studies", script) if os.path.exists(os.path.join(ROOT, "tests", "studies", script))
+           else os.path.join(ROOT, "tools", script)]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     return out.stdout

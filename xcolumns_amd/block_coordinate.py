@@ -144,7 +144,7 @@ class WavePolicy:
             # handful of decisions that fall the other way are already 1e-5 (20 K x 5 K: 1.0-1.7e-5 at 0.064 m
             # rows in flight, 4e-6 at half of that)
             # (linear below 30 K labels since the fuzz of round 2: 31 K x 7 K, k = 3 measured 1.2-1.5e-5 at 358 wavefronts
-            # and 4-7e-6 at 225 with the square root; tools/r02_fuzz_case.py 1042)
+            # and 4-7e-6 at 225 with the square root; tests/studies/fuzz_case.py 1042)
             small_m = min(1.0, float(m) / 30000.0)
             # (longer rows than 50 entries narrow the sweep -- more candidates per row meet a row in flight; shorter ones
             # do not widen it: 10 entries per row at 5x measured 2.6e-5 in sweep 1 on 31 K x 7 K)
