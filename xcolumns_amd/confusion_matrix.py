@@ -109,8 +109,9 @@ _BUCKETED_MAX_LABELS = 16384 * 2048   # XC_CF_BUCKETS_MAX x XC_CF_BUCKET_LABELS_
 _PRED_SIDE_MIN_ITEMS = 1_000_000      # below this the general kernel's single pass is as fast
 
 
-def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR) -> torch.Tensor:
-    """tp | fp | fn as a (3, m) float64 tensor on the GPU."""
+def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR, keeps: bool = True) -> torch.Tensor:
+    """tp | fp | fn as a (3, m) float64 tensor on the GPU.  `keeps`: `t` is an object the caller holds on to (a
+    DeviceCSR of theirs), so what is derived from it alone -- column sums, the row check -- pays off on later calls."""
     out = torch.zeros((3, t.m), dtype=torch.float64, device=t.data.device)
     # many contributions: counting-sort them by label bucket and sum in LDS instead of one global atomic each
     # (xc_confusion_csr_bucketed; the memory side retires ~23.5 G scattered adds/s).  XCOLUMNS_CONFUSION_BUCKETED=0/1 forces.
@@ -131,7 +132,7 @@ def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR) -> torch.Tensor:
     # sums the columns and checks the rows once).  A y_pred row that is not strictly ascending -- the reference's top-k
     # pads a short row with column 0 -- or a y_true that is not falls back to the general kernel.
     # XCOLUMNS_CONFUSION_PRED_SIDE=0 disables.
-    if (forced is None and os.environ.get("XCOLUMNS_CONFUSION_PRED_SIDE", "1") != "0" and t.n > 0
+    if (keeps and forced is None and os.environ.get("XCOLUMNS_CONFUSION_PRED_SIDE", "1") != "0" and t.n > 0
             and items >= _PRED_SIDE_MIN_ITEMS and t.nnz > 2 * p.nnz and t.rows_ascending()):
         out[2].copy_(t.column_sums())
         flag = torch.zeros(1, dtype=torch.int32, device=t.data.device)
@@ -194,7 +195,7 @@ def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
             p = D.DeviceCSR.from_torch(p.to_torch(torch.int64).t().to_sparse_csr(), dev)
         if p.data.dtype != t.data.dtype:
             p = D.DeviceCSR(p.indptr, p.indices, p.data.to(t.data.dtype), p.shape, p.max_row_nnz, p.min_row_nnz)
-        stats = confusion_csr_device(t, p)
+        stats = confusion_csr_device(t, p, keeps=isinstance(y_true, D.DeviceCSR) and axis == 0)
         home = dev
         is_torch = True
     else:
@@ -206,7 +207,7 @@ def _column_stats(y_true: Matrix, y_pred: Matrix, axis):
             y_true = y_true.astype(np.float64)
         t = D.DeviceCSR.from_scipy(y_true, dev)
         p = D.DeviceCSR.from_scipy(y_pred.astype(y_true.dtype, copy=False), dev)
-        stats = confusion_csr_device(t, p)
+        stats = confusion_csr_device(t, p, keeps=False)     # uploaded for this call: nothing to keep
         home = None
         is_torch = False
 
