@@ -290,6 +290,16 @@ def test_wave_policy_rules():
         assert s.next(400_000) == int(0.05 * 30_000 * 12_500 / 2 / 50_000)                      # its share of the changed rows
         g = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5)                                   # ~1 predicted row per label
         assert g.sequential and g.next(None) == 1 and g.next(10) == 1
+        # rules the round-2 fuzz added (profiles/r02_fuzz_concurrent.txt): all sequential under the per-sweep bar
+        assert bc.WavePolicy(37_000, m=20_000, row_nnz=30, k=2).sequential                          # < 8 rows per label on < 30 K labels
+        assert not bc.WavePolicy(37_000, m=20_000, row_nnz=30, k=2, parity="final").sequential
+        assert not bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5).sequential                     # configs[1]: 16.7 rows per label
+        assert bc.WavePolicy(35_000, m=40_000, row_nnz=12, k=7).sequential                          # budget above half of the row
+        assert p.next(None, greedy=True) == 1                                                       # greedy first sweep
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None, greedy=True) > 1
+        zs = bc.WavePolicy(40_000, m=40_000, row_nnz=50, k=5, skewed=True)
+        assert zs.sequential_below == 64 and zs.next(40_000) > 64 and zs.next(100) > 64 and bc.WavePolicy(40_000, m=40_000, row_nnz=50, k=5, skewed=True, scale=0.25).next(40_000) == 1             # a later sweep below 64 wavefronts
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=10, k=5).next(None) == p.next(None)          # short rows do not widen
         gf = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5, parity="final")
         # "final" parity takes the whole GPU there: the width does not move the difference on such a shape (r02_c3_width.txt)
         assert not gf.sequential and gf.next(None) == gf.cap and gf.next(10) == gf.cap
