@@ -294,20 +294,24 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         const int rounds = (int)wave_umax32((unsigned)want);
 #endif
         const unsigned my_bit = 1u << l16;
+        // A lane's wins take its list from the head, so after the rounds its selected entries are the first `cnt`
+        // slots of the sorted list: the entry masks of those prefixes are formed once, not tracked per round.
+        const unsigned pm1 = 1u << q0, pm2 = pm1 | (1u << q1), pm3 = pm2 | (1u << q2), pm4 = pm3 | (1u << q3);
+        unsigned cnt = 0u;
         // (no `round < want` test: a row with fewer than k entries runs out of non-zero heads by itself)
         for (int round = 0; round < rounds; ++round) {
             const unsigned M = row16_umax32(k0);
             const unsigned holders = seg16(__builtin_amdgcn_ballot_w64(k0 == M && k0 != 0u));
             const bool win = (holders & (0u - holders)) == my_bit; // lowest holder of this DPP row
-            selmask |= win ? (1u << q0) : 0u;
+            cnt += win ? 1u : 0u;
             k0 = win ? k1 : k0;
             k1 = win ? k2 : k1;
             k2 = win ? k3 : k2;
             k3 = win ? 0u : k3;
-            q0 = win ? q1 : q0;
-            q1 = win ? q2 : q1;
-            q2 = win ? q3 : q2;
         }
+#ifndef XC_EXP_TOPK_NOSELECT
+        selmask = cnt == 0u ? 0u : (cnt == 1u ? pm1 : (cnt == 2u ? pm2 : (cnt == 3u ? pm3 : pm4)));
+#endif
 #pragma unroll
         for (int c = 0; c < 4; ++c) sel[c] = (selmask >> c) & 1u;
 
@@ -315,11 +319,13 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         int32_t *o_idx = P.out_indices + row * k;
         float *o_dat = P.out_data ? P.out_data + row * k : nullptr;
         float *o_eta = (EXTRA && P.out_eta) ? P.out_eta + row * k : nullptr;
-        // selected entries held by the lower lanes of the DPP row, from the per-entry ballots
-        int before = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) before += __popc(seg16(__ballot(sel[c])) & ((1u << l16) - 1u));
-        int slot = before;
+        // selected entries held by the lower lanes of the DPP row: a prefix sum of the lanes' counts inside the row
+        unsigned mine = (unsigned)__popc(selmask), upto = mine;
+        upto += dpp_src<0x111, 0xF>(0u, upto); // row_shr:1
+        upto += dpp_src<0x112, 0xF>(0u, upto); // row_shr:2
+        upto += dpp_src<0x114, 0xF>(0u, upto); // row_shr:4
+        upto += dpp_src<0x118, 0xF>(0u, upto); // row_shr:8
+        int slot = (int)(upto - mine);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (sel[c] && live) {
