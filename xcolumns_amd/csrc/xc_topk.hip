@@ -258,7 +258,11 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
                 if (P.b) g = g + P.b[w_off + idx[c]];
             }
             gain[c] = g;
-            key[c] = valid ? sortable_key32(nan_to_neg_inf(g)) : 0u;
+            // (computed in all lanes, selected afterwards: left to itself hipcc wraps each entry's key in its own
+            // exec-masked block -- four saveexec / branch / restore sequences per iteration)
+            unsigned kk = sortable_key32(nan_to_neg_inf(g));
+            asm volatile("" : "+v"(kk));
+            key[c] = valid ? kk : 0u;
             sel[c] = false;
         }
         const int want = r < k ? r : k; // :465-466: a row of at most k entries keeps them all
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(XC_BLOCK) void topk_csr_q4_kernel(TopkParams<float>
         selmask = l16 < want ? 1u : 0u;
 #else
         // the four rows of a wave may need different numbers of rounds: run the maximum
-        const int rounds = (int)wave_umax32((unsigned)want);
+        // (all four rows hold at least k entries in the common case: one ballot instead of a wave reduction)
+        const int rounds = __ballot(r < k) == 0ull ? k : (int)wave_umax32((unsigned)want);
 #endif
         const unsigned my_bit = 1u << l16;
         // A lane's wins take its list from the head, so after the rounds its selected entries are the first `cnt`
