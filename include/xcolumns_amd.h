@@ -623,6 +623,39 @@ int xc_coverage_sweep_csr(int64_t n_order, const int32_t *order, const int32_t *
 int xc_coverage_product(int64_t n_k, const int32_t *pred_indices, const void *pred_eta, int dtype,
                         double *ef, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * The ORDERED parallel sweep (csrc/xc_bca_ord.hip): the loop of block_coordinate.py:448-463 with thousands of
+ * rows in flight AND its sequential semantics -- every row decides on the statistics as the rows BEFORE it in
+ * the visiting order left them.  Replaces the one-wavefront sweep wherever the reference's own trajectory is
+ * wanted (xc_bca_sweep_csr with n_waves = 1 computes the same predictions one row at a time).
+ * The order is walked in windows of (workgroups x 16) rows; inside a window the rows iterate on
+ * "committed records + changes of the earlier rows of the window" until no decision moves (the fixed point is
+ * the sequential result), then the window commits.  One launch per sweep.
+ * ------------------------------------------------------------------------- */
+
+/* Rows in flight on this device: one 1024-thread workgroup (16 rows) per CU. */
+int xc_bca_ord_window(int *workgroups, int *window);
+
+/* Bytes of the workspace of xc_bca_ord_sweep: m labels, `total_cap` change-list entries over all labels,
+ * n_hot (<= 255) labels with dense tables, `workgroups` workgroups. */
+int xc_bca_ord_workspace_bytes(int64_t m, int64_t total_cap, int n_hot, int workgroups, int64_t *bytes);
+
+/* One full sweep over `order` (NULL: rows 0 .. n_order - 1); arguments as xc_bca_sweep_csr where the names agree
+ * (tpfp: the float64 records of the CURRENT prediction, updated in place; s_entry: the column sum per stored
+ * entry).  workspace: zeroed once by the caller, and again after an error.  lab_dir[m][2]: per label {offset of
+ * its change list in entries, capacity} or {-(h + 1), 0} for the label of hot slot h (hot_labels[h]): a label
+ * gets a dense table when a window holds many rows that store it.  epoch0 grows by 2^20 from launch to launch on
+ * one workspace (lists are tagged, never cleared).  changed (device, optional): += rows whose prediction changed.
+ * status_host[4] (the call blocks on the stream): positions of the order committed; error -- 0, or 1: a change
+ * list overflowed, positions from status_host[0] on are untouched and left to the caller (xc_bca_sweep_csr with
+ * n_waves = 1 continues the same sweep exactly), 2: barrier timeout, 3: iteration limit; iterations; windows. */
+int xc_bca_ord_sweep(void *workspace, int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
+                     const int32_t *indices, const void *data, int dtype, int max_row_nnz, int32_t *pred_indices,
+                     void *pred_eta, uint8_t *sel, const int32_t *orphans, int k, int64_t m, double *tpfp,
+                     const double *s_entry, const int32_t *lab_dir, int64_t total_cap, const int32_t *hot_labels,
+                     int n_hot, int workgroups, const xc_metric *metric_host, int maximize, int skip_tn,
+                     unsigned epoch0, int64_t *changed, int64_t *status_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,24 +288,26 @@ def _check_bca(P, meta, z, name, pred_key, tol):
     assert set(meta) == {"utilities", "iters", "time"}
 
 
-def test_bca_csr_anchor_exact():
+@pytest.mark.parametrize("ordered", [True, False])
+def test_bca_csr_anchor_exact(ordered):
     z = G.load("bca_csr_anchor_f32")
     Y = G.csr_from(z, "y")
-    P, meta = G.product_call_from_spec(G.spec_of(z), Y, bca_waves=1)
+    P, meta = G.product_call_from_spec(G.spec_of(z), Y, bca_waves=1, bca_ordered=ordered)
     _check_bca(P, meta, z, None, "pred", 1e-12)
     assert isinstance(P, csr_matrix) and P.dtype == Y.dtype
     _same_csr(P, G.csr_from(z, "pred"))
 
 
+@pytest.mark.parametrize("ordered", [True, False])   # the ordered parallel sweep / one wavefront: the same sequence
 @pytest.mark.parametrize("tag", ["f32", "f64"])
-def test_bca_csr_golden_exact(tag):
+def test_bca_csr_golden_exact(tag, ordered):
     z = G.load("bca_csr_" + tag)
     Yu, Yz, init = G.csr_from(z, "yu"), G.csr_from(z, "yz"), G.csr_from(z, "init")
     for name in [str(s) for s in z["names"]]:
         spec = G.spec_of(z, name)
         Y = Yz if spec.get("data") == "z" else Yu
         init_m = init.copy()
-        P, meta = G.product_call_from_spec(spec, Y, init_matrix=init_m, bca_waves=1)
+        P, meta = G.product_call_from_spec(spec, Y, init_matrix=init_m, bca_waves=1, bca_ordered=ordered)
         _check_bca(P, meta, z, name, "pred_" + name, 1e-12)
         assert P.dtype == Y.dtype and (np.diff(P.indptr) == spec["k"]).all()
         _same_csr(P, G.csr_from(z, "pred_" + name))

@@ -28,6 +28,9 @@ reference's signature so call sites stay source-compatible):
                    default sweep's time, still hundreds of times faster than one wavefront; `bca_waves=1` is
                    deterministic too).  Default False: the faster sweep whose result depends on timing in
                    a few rows (env XCOLUMNS_BCA_DETERMINISTIC).
+``bca_ordered``    False: exact sweeps (``bca_waves=1`` and the shapes the policy runs exactly) use ONE wavefront instead of
+                   the ordered parallel sweep (csrc/xc_bca_ord.hip: a window of rows in flight, iterated to the fixed
+                   point that IS the sequential result) -- same predictions, for cross-checks (env XCOLUMNS_BCA_ORDERED=0).
 ``bca_diagnostics`` True: ``meta`` also carries "wavefronts" and "rows_changed" per sweep
                    (by default ``meta`` has exactly the reference's keys).
 ``order_backend``  "numpy" (default: the reference's RNG stream, generated on the
@@ -288,6 +291,8 @@ class BcaCsrEngine:
         # bca_deterministic: concurrent sweeps run block-synchronously (csrc/xc_bca_det.hip): same seed, same bits
         self.deterministic = bool(deterministic)
         self._det_ws = None
+        # one-wavefront (exact) sweeps run as the ordered parallel sweep (csrc/xc_bca_ord.hip) where it applies
+        self.ordered = os.environ.get("XCOLUMNS_BCA_ORDERED", "1") != "0"
         self.gain_metric = gain_spec.to_c()
         self.utility_metric = utility_spec.to_c()
         self.maximize = bool(maximize)
@@ -522,6 +527,11 @@ class BcaCsrEngine:
                 self.sweep_deterministic(order, n_order, int(n_waves))
                 return
             n_waves = 1   # greedy first sweep, foreign labels, float64 scores: the sequential sweep is deterministic too
+        if int(n_waves) == 1 and self.can_sweep_ordered(n_order, greedy):
+            # the reference's sequence, thousands of rows in flight (csrc/xc_bca_ord.hip); same predictions as the
+            # one-wavefront sweep below
+            self.sweep_ordered(order, n_order)
+            return
         if not full:
             self.changed.zero_()
         # the packed stream serves the concurrent sweeps (its s is float32); greedy and one-wavefront (exact)
@@ -541,6 +551,100 @@ class BcaCsrEngine:
         # every row was visited: no orphan is left in any prediction
         if full:
             self.orphans = None
+
+    # -- ordered parallel sweep (csrc/xc_bca_ord.hip) ------------------------------------------------------
+    def can_sweep_ordered(self, n_order: int, greedy: bool) -> bool:
+        """The reference's sequential semantics with a window of rows in flight: full sweeps of rows of at most 256
+        stored entries (longer rows, greedy first sweeps and partial orders take the one-wavefront sweep).
+        XCOLUMNS_BCA_ORDERED=0 / `ordered=False` disables."""
+        return (self.ordered and not greedy and n_order >= self.csr.n and self.csr.n > 0
+                and int(self.csr.max_row_nnz) <= 256)
+
+    def _ordered_setup(self, orphans: Optional[torch.Tensor]):
+        """Label directory of the ordered sweep: which labels get a dense table (a window holds many rows that store
+        them) and how many change-list entries the others can hold (a row changes a label only if it stores it, or
+        holds it as an orphan of a foreign initial prediction)."""
+        c = self.csr
+        dev = self.dev
+        if getattr(self, "_ord_counts", None) is None:
+            wg, win = ctypes.c_int(0), ctypes.c_int(0)
+            _lib.call("xc_bca_ord_window", ctypes.byref(wg), ctypes.byref(win))
+            env_wg = os.environ.get("XCOLUMNS_BCA_ORD_WORKGROUPS")
+            self._ord_wg = max(1, min(int(env_wg), wg.value)) if env_wg else wg.value
+            self._ord_counts = torch.bincount(c.indices, minlength=c.m)
+            self._ord_epoch = 1 << 20
+            self._ord_dirs = {}
+        key = orphans is not None
+        if key in self._ord_dirs and not key:
+            return self._ord_dirs[key]
+        W = self._ord_wg * 16
+        counts = self._ord_counts
+        if orphans is not None:
+            counts = counts + torch.bincount(orphans[orphans >= 0], minlength=c.m)
+        readers = counts.to(torch.float64) * (float(W) / float(max(1, c.n)))     # expected rows of a window that store the label
+        # dense tables: a list of L entries read by L rows is L^2 entry reads, a table W slots scanned once
+        hot_min = float(os.environ.get("XCOLUMNS_BCA_ORD_HOT_READERS", "48"))
+        n_hot = int(min(255, int((readers >= hot_min).sum().item())))
+        if os.environ.get("XCOLUMNS_BCA_ORD_HOT", "1") == "0":
+            n_hot = 0
+        cap = torch.minimum(counts, 8 + 2 * torch.ceil(readers).to(torch.int64))
+        hot_labels = None
+        if n_hot > 0:
+            hot_labels = torch.topk(counts, n_hot).indices.to(torch.int32)
+            cap[hot_labels.long()] = 0
+        off = torch.cumsum(cap, 0) - cap
+        total_cap = int(cap.sum().item())
+        if total_cap >= (1 << 31):
+            raise ValueError("xcolumns_amd: the ordered sweep's change lists exceed 2^31 entries")
+        lab_dir = torch.stack([off, cap], dim=1).to(torch.int32)
+        if n_hot > 0:
+            lab_dir[hot_labels.long(), 0] = -(torch.arange(n_hot, device=dev, dtype=torch.int32) + 1)
+        nbytes = ctypes.c_int64(0)
+        _lib.call("xc_bca_ord_workspace_bytes", c.m, total_cap, n_hot, self._ord_wg, ctypes.byref(nbytes))
+        ws = torch.zeros(int(nbytes.value), dtype=torch.uint8, device=dev)
+        d = {"lab_dir": lab_dir.contiguous(), "hot_labels": hot_labels, "n_hot": n_hot, "total_cap": total_cap, "ws": ws}
+        self._ord_dirs[key] = d
+        return d
+
+    def sweep_ordered(self, order: Optional[torch.Tensor], n_order: int):
+        """One full sweep with the reference's visiting-order semantics (block_coordinate.py:448-463) and a window of
+        rows in flight (xc_bca_ord_sweep).  Updates the prediction and the float64 records; the boundary statistics
+        are rebuilt from the prediction afterwards (recompute_utility_sum), as the reference does (:465-467)."""
+        c = self.csr
+        self._ensure_s_entry()
+        d = self._ordered_setup(self.orphans)
+        self.changed.zero_()
+        status = (ctypes.c_int64 * 4)(0, 0, 0, 0)
+        if self._ord_epoch >= (1 << 31) - (1 << 21):      # the lists' iteration tags wrap: start over on cleared lists
+            for dd in self._ord_dirs.values():
+                dd["ws"].zero_()
+            self._ord_epoch = 1 << 20
+        _lib.call("xc_bca_ord_sweep", D.ptr(d["ws"]), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
+                  D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta),
+                  D.ptr(self.sel), D.ptr(self.orphans), self.k, c.m, D.ptr(self.tpfp), D.ptr(self.s_entry), D.ptr(d["lab_dir"]),
+                  d["total_cap"], D.ptr(d["hot_labels"]), d["n_hot"], self._ord_wg, ctypes.byref(self.gain_metric),
+                  int(self.maximize), int(self.skip_tn), ctypes.c_uint32(self._ord_epoch), D.ptr(self.changed), status,
+                  D.stream())
+        self._ord_epoch += 1 << 20
+        done, err = int(status[0]), int(status[1])
+        self.ordered_stats = {"iterations": int(status[2]), "windows": int(status[3]), "done": done, "error": err}
+        if err == 1:
+            # a change list overflowed (more rows of one window changed a label than its list holds): the committed
+            # prefix stands, the one-wavefront sweep walks the rest of the order -- the same sweep, exactly
+            d["ws"].zero_()
+            rest = (order if order is not None else torch.arange(n_order, dtype=torch.int32, device=self.dev))[done:]
+            _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(rest), int(n_order - done), D.ptr(self.orphans), 0, 1, 0,
+                      0, D.ptr(self.changed), D.stream())
+        elif err != 0:
+            d["ws"].zero_()
+            raise RuntimeError(f"ordered BCA sweep failed (status {err}: "
+                               f"{'barrier timeout' if err == 2 else 'iteration limit'}) after {done} rows")
+        if self.orphans is not None:
+            self._ord_dirs.pop(True, None)        # the directory with the orphans' allowance served its one sweep
+        self._pack_dirty = True          # sel was rewritten without touching the packed copy
+        self._acc_filled = False         # the boundary statistics come from the prediction (a from-scratch pass)
+        self._partial_sweep = True       # rows_changed() reads the kernel's counter
+        self.orphans = None
 
     # -- deterministic concurrent sweep ----------------------------------------------------------------
     def can_sweep_deterministic(self) -> bool:
@@ -1134,7 +1238,7 @@ def _initial_csr_indices(y_proba, init_y_pred, k: int, seed):
 
 def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
             init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves, order_backend,
-            bca_parity=None, bca_deterministic=False):
+            bca_parity=None, bca_deterministic=False, bca_ordered=None):
     """Sparse y_proba: a csr_matrix in host memory (uploaded here, result downloaded) or a matrix already
     resident in HBM -- DeviceCSR or torch sparse_csr tensor -- in which case nothing crosses PCIe but the
     visiting orders and the per-sweep utility."""
@@ -1159,6 +1263,8 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
         csr = D.as_device_csr(y_proba, dev)
         eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,
                            deterministic=bca_deterministic)
+        if bca_ordered is not None:
+            eng.ordered = bool(bca_ordered)
 
         log_info("  Initializing initial prediction ...", verbose)
         greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"
@@ -1413,11 +1519,12 @@ def predict_using_bc_with_0approx(
     bca_diagnostics = kwargs.pop("bca_diagnostics", False)
     bca_deterministic = bool(kwargs.pop("bca_deterministic", os.environ.get("XCOLUMNS_BCA_DETERMINISTIC", "0") == "1"))
     order_backend = kwargs.pop("order_backend", os.environ.get("XCOLUMNS_ORDER_BACKEND", "numpy"))
+    bca_ordered = kwargs.pop("bca_ordered", None)
 
     if is_sparse(y_proba):
         y_pred = _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                          init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, bca_waves,
-                         order_backend, bca_parity, bca_deterministic)
+                         order_backend, bca_parity, bca_deterministic, bca_ordered)
     else:
         y_pred = _bc_dense(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximize, tolerance,
                            init_y_pred, max_iters, shuffle_order, skip_tn, seed, verbose, meta, order_backend,
