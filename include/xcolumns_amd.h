@@ -633,28 +633,33 @@ int xc_coverage_product(int64_t n_k, const int32_t *pred_indices, const void *pr
  * the sequential result), then the window commits.  One launch per sweep.
  * ------------------------------------------------------------------------- */
 
-/* Rows in flight on this device: one 1024-thread workgroup (16 rows) per CU. */
+/* Workgroups of an ordered sweep on this device (one 1024-thread workgroup = 16 wavefronts per CU) and the rows in
+ * flight with ONE row per wavefront; a sweep holds rows_per_wave times as many. */
 int xc_bca_ord_window(int *workgroups, int *window);
 
 /* Bytes of the workspace of xc_bca_ord_sweep: m labels, `total_cap` change-list entries over all labels,
- * n_hot (<= 255) labels with dense tables, `workgroups` workgroups. */
-int xc_bca_ord_workspace_bytes(int64_t m, int64_t total_cap, int n_hot, int workgroups, int64_t *bytes);
+ * n_hot (<= 255) labels with dense tables, windows of `window` = workgroups x 16 x rows_per_wave rows. */
+int xc_bca_ord_workspace_bytes(int64_t m, int64_t total_cap, int n_hot, int window, int64_t *bytes);
 
 /* One full sweep over `order` (NULL: rows 0 .. n_order - 1); arguments as xc_bca_sweep_csr where the names agree
  * (tpfp: the float64 records of the CURRENT prediction, updated in place; s_entry: the column sum per stored
  * entry).  workspace: zeroed once by the caller, and again after an error.  lab_dir[m][2]: per label {offset of
  * its change list in entries, capacity} or {-(h + 1), 0} for the label of hot slot h (hot_labels[h]): a label
- * gets a dense table when a window holds many rows that store it.  epoch0 grows by 2^20 from launch to launch on
- * one workspace (lists are tagged, never cleared).  changed (device, optional): += rows whose prediction changed.
- * status_host[4] (the call blocks on the stream): positions of the order committed; error -- 0, or 1: a change
- * list overflowed, positions from status_host[0] on are untouched and left to the caller (xc_bca_sweep_csr with
- * n_waves = 1 continues the same sweep exactly), 2: barrier timeout, 3: iteration limit; iterations; windows. */
+ * gets a dense table when a window holds many rows that store it.  rows_per_wave: 1, 2 or 4 rows per wavefront
+ * (rows x candidates per lane <= 4 fit the registers: lowered for rows of more than 64 entries); the workspace must
+ * have been sized for the window this gives.  epoch0 grows by 2^20 from launch to launch on one workspace (lists
+ * are tagged, never cleared).  changed (device, optional): += rows whose prediction changed.
+ * status_host[8] (the call blocks on the stream): [0] positions of the order committed; [1] error -- 0, or 1: a
+ * change list overflowed, positions from status_host[0] on are untouched and left to the caller (xc_bca_sweep_csr
+ * with n_waves = 1 continues the same sweep exactly), 2: barrier timeout, 3: iteration limit; [2] iterations;
+ * [3] windows; [4] / [5] 100 MHz ticks workgroup 0 spent in grid barriers / in the kernel; [6] rows per wavefront
+ * used. */
 int xc_bca_ord_sweep(void *workspace, int64_t n_order, const int32_t *order, int64_t n_norm, const int32_t *indptr,
                      const int32_t *indices, const void *data, int dtype, int max_row_nnz, int32_t *pred_indices,
                      void *pred_eta, uint8_t *sel, const int32_t *orphans, int k, int64_t m, double *tpfp,
                      const double *s_entry, const int32_t *lab_dir, int64_t total_cap, const int32_t *hot_labels,
-                     int n_hot, int workgroups, const xc_metric *metric_host, int maximize, int skip_tn,
-                     unsigned epoch0, int64_t *changed, int64_t *status_host, void *stream);
+                     int n_hot, int workgroups, int rows_per_wave, const xc_metric *metric_host, int maximize,
+                     int skip_tn, unsigned epoch0, int64_t *changed, int64_t *status_host, void *stream);
 
 #ifdef __cplusplus
 }

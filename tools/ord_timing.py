@@ -35,7 +35,7 @@ def timed(self, order, n_order):
     t0 = time.perf_counter()
     orig(self, order, n_order)
     torch.cuda.synchronize()
-    stats.append(dict(self.ordered_stats, ms=(time.perf_counter() - t0) * 1e3, n_hot=self._ord_dirs[False]["n_hot"] if False in self._ord_dirs else -1))
+    stats.append(dict(self.ordered_stats, ms=(time.perf_counter() - t0) * 1e3))
 
 
 bc.BcaCsrEngine.sweep_ordered = timed
@@ -50,7 +50,8 @@ print(f"{args.workload}{' zipf' if args.zipf else ''}: whole call {wall:.1f} ms 
       f"({n * args.sweeps / wall * 1e3:.3e} rows/s)")
 for j, s in enumerate(stats):
     print(f"  sweep {j + 1}: {s['ms']:.3f} ms  {s['iterations']} iterations in {s['windows']} windows  "
-          f"({n / s['ms'] * 1e3:.3e} rows/s; hot tables {s['n_hot']}; status {s['error']})")
+          f"({n / s['ms'] * 1e3:.3e} rows/s; window {s['window']}; hot tables {s['n_hot']}; kernel {s['kernel_us'] / 1e3:.3f} ms, "
+          f"{s['barrier_us'] / 1e3:.3f} ms of it in barriers; status {s['error']})")
 print("  utilities", [f"{u:.12f}" for u in meta["utilities"]])
 if args.one_wave:
     t0 = time.perf_counter()

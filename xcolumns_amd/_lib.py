@@ -152,7 +152,7 @@ SIGNATURES = {
     "xc_bca_ord_workspace_bytes": (c_int, [c_int64, c_int64, c_int, c_int, POINTER(c_int64)]),
     "xc_bca_ord_sweep": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
-                                 c_void_p, c_int, c_int, POINTER(XcMetric), c_int, c_int, ctypes.c_uint32, c_void_p,
+                                 c_void_p, c_int, c_int, c_int, POINTER(XcMetric), c_int, c_int, ctypes.c_uint32, c_void_p,
                                  POINTER(c_int64), c_void_p]),
 }
 

@@ -571,13 +571,23 @@ class BcaCsrEngine:
             _lib.call("xc_bca_ord_window", ctypes.byref(wg), ctypes.byref(win))
             env_wg = os.environ.get("XCOLUMNS_BCA_ORD_WORKGROUPS")
             self._ord_wg = max(1, min(int(env_wg), wg.value)) if env_wg else wg.value
+            self._ord_waves = max(1, win.value // max(1, wg.value))            # wavefronts per workgroup
+            self._ord_max_rpw = 4 if self._ord_waves >= 16 else 8              # rows x candidates per lane a wavefront's registers hold
+            # rows per wavefront: rows x candidates per lane <= 4 stay in registers for a window's iterations; small
+            # matrices take fewer (a window should not swallow the whole sweep: its first rows would wait for nothing)
+            rpw = int(os.environ.get("XCOLUMNS_BCA_ORD_ROWS", "2"))   # measured: profiles/r03_ordered_builds_rows.txt
+            ch = 1 if c.max_row_nnz <= 64 else (2 if c.max_row_nnz <= 128 else 4)
+            rpw = max(1, min(8 if rpw >= 8 else (4 if rpw >= 4 else (2 if rpw >= 2 else 1)), self._ord_max_rpw // ch))
+            while rpw > 1 and self._ord_wg * self._ord_waves * rpw * 2 > max(1, c.n):
+                rpw //= 2
+            self._ord_rpw = rpw
             self._ord_counts = torch.bincount(c.indices, minlength=c.m)
             self._ord_epoch = 1 << 20
             self._ord_dirs = {}
         key = orphans is not None
         if key in self._ord_dirs and not key:
             return self._ord_dirs[key]
-        W = self._ord_wg * 16
+        W = self._ord_wg * self._ord_waves * self._ord_rpw
         counts = self._ord_counts
         if orphans is not None:
             counts = counts + torch.bincount(orphans[orphans >= 0], minlength=c.m)
@@ -600,7 +610,7 @@ class BcaCsrEngine:
         if n_hot > 0:
             lab_dir[hot_labels.long(), 0] = -(torch.arange(n_hot, device=dev, dtype=torch.int32) + 1)
         nbytes = ctypes.c_int64(0)
-        _lib.call("xc_bca_ord_workspace_bytes", c.m, total_cap, n_hot, self._ord_wg, ctypes.byref(nbytes))
+        _lib.call("xc_bca_ord_workspace_bytes", c.m, total_cap, n_hot, W, ctypes.byref(nbytes))
         ws = torch.zeros(int(nbytes.value), dtype=torch.uint8, device=dev)
         d = {"lab_dir": lab_dir.contiguous(), "hot_labels": hot_labels, "n_hot": n_hot, "total_cap": total_cap, "ws": ws}
         self._ord_dirs[key] = d
@@ -614,7 +624,7 @@ class BcaCsrEngine:
         self._ensure_s_entry()
         d = self._ordered_setup(self.orphans)
         self.changed.zero_()
-        status = (ctypes.c_int64 * 4)(0, 0, 0, 0)
+        status = (ctypes.c_int64 * 8)()
         if self._ord_epoch >= (1 << 31) - (1 << 21):      # the lists' iteration tags wrap: start over on cleared lists
             for dd in self._ord_dirs.values():
                 dd["ws"].zero_()
@@ -622,12 +632,14 @@ class BcaCsrEngine:
         _lib.call("xc_bca_ord_sweep", D.ptr(d["ws"]), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta),
                   D.ptr(self.sel), D.ptr(self.orphans), self.k, c.m, D.ptr(self.tpfp), D.ptr(self.s_entry), D.ptr(d["lab_dir"]),
-                  d["total_cap"], D.ptr(d["hot_labels"]), d["n_hot"], self._ord_wg, ctypes.byref(self.gain_metric),
+                  d["total_cap"], D.ptr(d["hot_labels"]), d["n_hot"], self._ord_wg, self._ord_rpw, ctypes.byref(self.gain_metric),
                   int(self.maximize), int(self.skip_tn), ctypes.c_uint32(self._ord_epoch), D.ptr(self.changed), status,
                   D.stream())
         self._ord_epoch += 1 << 20
         done, err = int(status[0]), int(status[1])
-        self.ordered_stats = {"iterations": int(status[2]), "windows": int(status[3]), "done": done, "error": err}
+        self.ordered_stats = {"iterations": int(status[2]), "windows": int(status[3]), "done": done, "error": err,
+                              "barrier_us": status[4] / 100.0, "kernel_us": status[5] / 100.0, "rows_per_wave": int(status[6]),
+                              "window": self._ord_wg * self._ord_waves * int(status[6]), "n_hot": d["n_hot"]}
         if err == 1:
             # a change list overflowed (more rows of one window changed a label than its list holds): the committed
             # prefix stands, the one-wavefront sweep walks the rest of the order -- the same sweep, exactly
