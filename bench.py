@@ -556,6 +556,15 @@ def worker(args):
                     torch.cuda.empty_cache()
             except Exception as e:
                 out["zipf"] = {"error": repr(e)}
+        # (5) the shapes whose default sweeps are the EXACT ones (the ordered parallel sweep, csrc/xc_bca_ord.hip): BASELINE
+        #     configs[2] (about one predicted row per label) and configs[1] with Zipf(1) labels -- ONE public call each
+        for key, wl, zf, sw in (("c3", "c3_amazon670k_150Kx670K", False, args.steps), ("c2_zipf", "c2_100Kx30K", True, 5)):
+            if args.workload == wl and bool(args.zipf) == zf:
+                continue
+            try:
+                out[key] = shape_leg(wl, zf, sw)
+            except Exception as e:
+                out[key] = {"error": repr(e)}
         # (4) per-sweep |utility - sequential oracle| of the default policy on configs[1] (C2: the oracle takes seconds)
         try:
             out["parity_c2"] = parity_leg()
@@ -607,6 +616,59 @@ def api_call_leg(Y, sweeps):
         med = float(np.median(times[1:]))
         res[name] = {"ms": med * 1e3, "rows_per_s": n * sweeps / med, "ms_min": min(times[1:]) * 1e3,
                      "ms_max": max(times[1:]) * 1e3, "calls": len(times) - 1}
+    return res
+
+
+def shape_leg(workload, zipf, sweeps, oracle_sweeps=3):
+    """ONE public predict_optimizing_macro_f1_score_using_bc call (default policy, matrix resident in HBM, the
+    reference's numpy visiting order) on another shape: wall time, rows/s, which sweep ran how (wavefronts; the exact
+    sweeps' windows and iterations), and |utility - sequential oracle| for the first sweeps."""
+    import torch
+
+    from oracle import ref as oracle_ref
+    from xcolumns_amd import _device as D
+    from xcolumns_amd import block_coordinate as bc
+    from xcolumns_amd.synthetic import WORKLOADS, make_csr_rows
+
+    n, m = WORKLOADS[workload]
+    Y = make_csr_rows(n, m, 0, n, R_NNZ, seed=MATRIX_SEED, zipf=zipf, k=K)
+    Yd = D.DeviceCSR.from_scipy(Y)
+    f = bc.predict_optimizing_macro_f1_score_using_bc
+    seen = []
+    orig = bc.BcaCsrEngine.sweep_ordered
+
+    def spy(self, order, n_order):
+        orig(self, order, n_order)
+        seen.append(dict(self.ordered_stats))
+
+    times, meta = [], None
+    bc.BcaCsrEngine.sweep_ordered = spy
+    try:
+        for _ in range(4):
+            seen.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            P, meta = f(Yd, K, tolerance=-1.0, max_iters=sweeps, seed=ORDER_SEED, return_meta=True, bca_diagnostics=True)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    finally:
+        bc.BcaCsrEngine.sweep_ordered = orig
+    med = float(np.median(times[1:]))
+    res = {"workload": f"{workload}{' with Zipf(1) labels' if zipf else ''}: n={n}, m={m}, {R_NNZ} entries/row, k={K}, {sweeps} sweeps, "
+                       "default policy, one public call on a matrix resident in HBM",
+           "ms": med * 1e3, "rows_per_s": n * sweeps / med, "ms_min": min(times[1:]) * 1e3, "ms_max": max(times[1:]) * 1e3,
+           "roofline_frac_of_the_call": algorithmic_bytes_per_row_sweep(R_NNZ, K) * n * sweeps / med / 1e9 / HBM_PEAK_GBS,
+           "wavefronts_per_sweep": meta.get("wavefronts"),
+           "exact_sweeps": [{"window_rows": s_["window"], "windows": s_["windows"], "iterations": s_["iterations"],
+                             "kernel_ms": s_["kernel_us"] / 1e3, "barrier_ms": s_["barrier_us"] / 1e3} for s_ in seen],
+           "utility_by_sweep": meta["utilities"]}
+    q = min(sweeps, oracle_sweeps)
+    metric = oracle_ref.make_metric(oracle_ref.FBETA, k=float(K), m=float(m))
+    Po, mo = oracle_ref.predict_using_bc_with_0approx(Y, metric, K, skip_tn=True, seed=ORDER_SEED, max_iters=q, tolerance=-1.0)
+    d = np.abs(np.asarray(meta["utilities"][:q]) - np.asarray(mo["utilities"]))
+    res["abs_diff_vs_oracle_by_sweep"] = [float(x) for x in d]
+    if sweeps == q:
+        res["prediction_equals_oracle"] = bool(np.array_equal(P.indices.cpu().numpy(), Po.indices))
     return res
 
 

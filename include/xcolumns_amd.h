@@ -375,29 +375,6 @@ int xc_bca_delta_unpack(int64_t m2, double *tpfp, double *base, double *count, c
  *                    (default 0.05; sets how often a narrow sweep publishes them). */
 int xc_bca_set_tuning(double conflict_rel, double hot_unpublished);
 
-/* ---- deterministic concurrent sweep (csrc/xc_bca_det.hip) --------------------------------------------------------
- * Same `seed` => the same prediction, bit for bit, with many rows in flight: the order is walked in blocks of up to
- * `block` rows (<= 8192); a block scores its rows on the records as they stood when it began, rows claim the labels
- * they want to add or drop (those with fewer than 512 predicted rows) with integer atomics, a row commits only if it
- * holds every claim, losers are carried into the next block as its most senior rows; the records of the sweep and
- * the from-scratch statistics of the boundary are integer (2^-38 fixed point) sums.  float32 scores over the packed
- * row stream (xc_bca_pack_rows*); no greedy sweep, no orphans.
- *   xc_bca_det_workspace_bytes  size of the device workspace for a matrix with rows of <= max_row_nnz entries
- *   xc_bca_det_begin            start a sweep (clears claims, statistics, cursor; records <- tpfp[m][2], float64)
- *   xc_bca_det_blocks           run `iterations` blocks; progress_host (optional, blocks on the stream) receives
- *                               {positions of the order consumed, rows of the last block}: the sweep is over when
- *                               all n_order positions are consumed and the last block was empty
- *   xc_bca_det_finish           acc[2m + 1] (float64) <- the sweep's from-scratch {tp, fp} and changed-row count:
- *                               the input of xc_bca_commit_utility */
-int xc_bca_det_workspace_bytes(int max_row_nnz, int64_t m, int64_t *bytes);
-int xc_bca_det_begin(void *workspace, int64_t m, const double *tpfp, void *stream);
-int xc_bca_det_blocks(void *workspace, int64_t n_order, const int32_t *order, int64_t n_norm,
-                      const int32_t *indptr, int max_row_nnz, int32_t *pred_indices, float *pred_eta,
-                      uint8_t *sel, int k, int64_t m, void *packed,
-                      const xc_metric *metric_host, int maximize, int skip_tn, int block, int iterations,
-                      int64_t *progress_host, void *stream);
-int xc_bca_det_finish(void *workspace, int64_t m, double *acc, void *stream);
-
 /* Host-side: one `Generator.shuffle(order)` of numpy's PCG64 stream -- the reference's visiting order of a sweep
  * (block_coordinate.py:413-419) -- in place on an int32 array of n entries (host memory).  state_io =
  * {state_hi, state_lo, inc_hi, inc_lo} of rng.bit_generator.state["state"], has_uint32_io / uinteger_io the

@@ -379,3 +379,25 @@ def test_sharded_bca_short_row_raises_on_every_rank():
     res = _spawn(_short_row_worker, 2)
     for _, msg in res:
         assert msg is not None and "at least k=4" in msg and "has 1" in msg, msg
+
+
+def _policy_inputs_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xcolumns_amd.distributed import TorchComm, global_policy_inputs
+
+    # rank 0 holds a skewed shard with short rows, rank 1 a uniform one with long rows
+    skewed_local, nnz_local = (True, 1000 * 12) if rank == 0 else (False, 3000 * 50)
+    out = global_policy_inputs(TorchComm(), skewed_local, nnz_local, 4000)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_policy_inputs_are_global():
+    """Every rank feeds the wavefront policy the same inputs (skewed anywhere = skewed; entries per row over all
+    rows): ranks that chose different sweep paths would issue different collectives."""
+    res = _spawn(_policy_inputs_worker, 2)
+    assert res[0][1] == res[1][1] == (True, (1000 * 12 + 3000 * 50) / 4000)

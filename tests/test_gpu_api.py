@@ -146,34 +146,42 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.parametrize("zipf", [False, True])
-def test_deterministic_concurrent_mode(oref, zipf):
-    """bca_deterministic=True: two runs with the same seed return the same prediction and the same utilities BIT
-    FOR BIT (the default mode differs in a few rows run to run), with many rows in flight per block; the parity
-    bars against the sequential oracle are the default mode's; the reported utility is the utility of what is
-    returned."""
-    from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
+def test_deterministic_mode_is_the_reference_sequence(oref, zipf):
+    """bca_deterministic=True: every sweep is the ordered parallel sweep -- the reference's own sequence, which is
+    deterministic given `seed` (block_coordinate.py:413-419): runs with the same seed return the same prediction,
+    it is the sequential oracle's prediction, and the utilities are the oracle's to 1e-12 (the default mode differs
+    in a few rows run to run).  Thousands of rows are in flight meanwhile (not one wavefront)."""
+    from xcolumns_amd import block_coordinate as bc
     from xcolumns_amd.synthetic import make_csr
 
+    f = bc.predict_optimizing_macro_f1_score_using_bc
     n, m, r, k = 60000, 20000, 40, 5
     Y = make_csr(n, m, r, seed=77, zipf=zipf, k=k)
     metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
-    _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=5, max_iters=4, tolerance=-1.0)
-    runs = [f(Y, k, seed=5, max_iters=4, tolerance=-1.0, return_meta=True, bca_deterministic=True, bca_diagnostics=True)
-            for _ in range(3)]
+    Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=5, max_iters=4, tolerance=-1.0)
+    seen = []
+    orig = bc.BcaCsrEngine.sweep_ordered
+
+    def spy(self, order, n_order):
+        orig(self, order, n_order)
+        seen.append(dict(self.ordered_stats))
+
+    bc.BcaCsrEngine.sweep_ordered = spy
+    try:
+        runs = [f(Y, k, seed=5, max_iters=4, tolerance=-1.0, return_meta=True, bca_deterministic=True) for _ in range(3)]
+    finally:
+        bc.BcaCsrEngine.sweep_ordered = orig
+    assert len(seen) == 12 and all(s_["error"] == 0 and s_["window"] >= 4096 for s_ in seen)
     P0, m0 = runs[0]
-    assert max(m0["wavefronts"]) > 1                    # it is a concurrent mode
     for P, mt in runs[1:]:
-        assert np.array_equal(P.indices, P0.indices) and mt["utilities"] == m0["utilities"]
+        assert np.array_equal(P.indices, P0.indices)
+        assert np.allclose(mt["utilities"], m0["utilities"], rtol=0, atol=1e-14)
+    assert np.array_equal(P0.indices, Po.indices)
     d = np.abs(np.asarray(m0["utilities"]) - np.asarray(mo["utilities"]))
-    print("deterministic mode, blocks of", m0["wavefronts"], "rows; |utility - oracle| per sweep:", d)
-    assert d.max() < 1e-5
+    print("deterministic mode: windows of", seen[0]["window"], "rows,", [s_["iterations"] for s_ in seen[:4]],
+          "iterations per sweep; |utility - oracle| per sweep:", d)
+    assert d.max() < 1e-12
     assert (np.diff(P0.indptr) == k).all() and (np.diff(P0.indices.reshape(n, k), axis=1) > 0).all()
-    tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, P0, skip_tn=True)
-    assert abs(oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n) - m0["utilities"][-1]) < 1e-11
-    # a fixed block size works the same way
-    a = f(Y, k, seed=5, max_iters=2, tolerance=-1.0, bca_deterministic=True, bca_waves=512)
-    b = f(Y, k, seed=5, max_iters=2, tolerance=-1.0, bca_deterministic=True, bca_waves=512)
-    assert np.array_equal(a.indices, b.indices)
 
 
 @pytest.mark.parametrize("delta", ["1", "0"])

@@ -127,12 +127,6 @@ SIGNATURES = {
     "xc_scatter_sum_f32": (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "xc_label_busy_list": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_exchange_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "xc_bca_det_workspace_bytes": (c_int, [c_int, c_int64, POINTER(c_int64)]),
-    "xc_bca_det_begin": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
-    "xc_bca_det_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                  c_int, c_int64, c_void_p, POINTER(XcMetric), c_int, c_int, c_int, c_int,
-                                  POINTER(c_int64), c_void_p]),
-    "xc_bca_det_finish": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "xc_host_shuffle_pcg64": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint32), c_int64, c_void_p]),
     "xc_host_shuffle_draws": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint32), c_int64, c_void_p]),
     "xc_host_shuffle_apply": (c_int, [c_int64, c_void_p, c_void_p]),

@@ -23,11 +23,11 @@ reference's signature so call sites stay source-compatible):
                    one-wavefront sweep; "final": wider sweeps, the whole GPU on those shapes too, the bar holds for
                    the utility after the last sweep -- on the one-row-per-label shapes: within the reference's own
                    seed-to-seed spread (:class:`WavePolicy`; env XCOLUMNS_BCA_PARITY).
-``bca_deterministic`` True: same `seed` => the same prediction, bit for bit, run to run, with many rows in flight
-                   (block-synchronous sweeps, csrc/xc_bca_det.hip; sparse float32 y_proba; several times the
-                   default sweep's time, still hundreds of times faster than one wavefront; `bca_waves=1` is
-                   deterministic too).  Default False: the faster sweep whose result depends on timing in
-                   a few rows (env XCOLUMNS_BCA_DETERMINISTIC).
+``bca_deterministic`` True: every sweep runs as the reference's own sequence (the ordered parallel sweep, csrc/xc_bca_ord.hip:
+                   a window of rows in flight iterated to the sequential fixed point) -- the reference is deterministic given
+                   `seed` (:413-419), and so is the prediction then, run to run; several times the default sweep's time.
+                   Default False: the faster concurrent sweep whose result depends on timing in a few rows
+                   (env XCOLUMNS_BCA_DETERMINISTIC).
 ``bca_ordered``    False: exact sweeps (``bca_waves=1`` and the shapes the policy runs exactly) use ONE wavefront instead of
                    the ordered parallel sweep (csrc/xc_bca_ord.hip: a window of rows in flight, iterated to the fixed
                    point that IS the sequential result) -- same predictions, for cross-checks (env XCOLUMNS_BCA_ORDERED=0).
@@ -288,9 +288,8 @@ class BcaCsrEngine:
                 f"(shortest row has {int(csr.min_row_nnz)})")
         self.csr = csr
         self.k = int(k)
-        # bca_deterministic: concurrent sweeps run block-synchronously (csrc/xc_bca_det.hip): same seed, same bits
+        # bca_deterministic: every sweep is the exact (ordered) one -- the reference's sequence, same seed same prediction
         self.deterministic = bool(deterministic)
-        self._det_ws = None
         # one-wavefront (exact) sweeps run as the ordered parallel sweep (csrc/xc_bca_ord.hip) where it applies
         self.ordered = os.environ.get("XCOLUMNS_BCA_ORDERED", "1") != "0"
         self.gain_metric = gain_spec.to_c()
@@ -522,11 +521,8 @@ class BcaCsrEngine:
         kernel clears it)."""
         c = self.csr
         full = n_order >= c.n
-        if self.deterministic and int(n_waves) > 1:
-            if not greedy and full and self.can_sweep_deterministic():
-                self.sweep_deterministic(order, n_order, int(n_waves))
-                return
-            n_waves = 1   # greedy first sweep, foreign labels, float64 scores: the sequential sweep is deterministic too
+        if self.deterministic:
+            n_waves = 1
         if int(n_waves) == 1 and self.can_sweep_ordered(n_order, greedy):
             # the reference's sequence, thousands of rows in flight (csrc/xc_bca_ord.hip); same predictions as the
             # one-wavefront sweep below
@@ -544,6 +540,8 @@ class BcaCsrEngine:
         _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(order), int(n_order), D.ptr(self.orphans),
                   int(bool(greedy)), int(n_waves), int(full), int(use_packed),
                   None if full else D.ptr(self.changed), D.stream())
+        if not full and self.shadow is not None and int(n_waves) == 1 and not greedy:
+            self.shadow.copy_(self.tpfp)     # an exact partial sweep updated the float64 records only
         if not use_packed:
             self._pack_dirty = True  # sel was rewritten without touching the packed copy
         self._acc_filled = full
@@ -552,13 +550,45 @@ class BcaCsrEngine:
         if full:
             self.orphans = None
 
+    # -- row shards, host-paced sweeps: exchanges inside the sweep ------------------------------------------
+    supports_segments = True
+
+    def sweep_segments(self, order: Optional[torch.Tensor], n_order: int, n_waves: int, n_seg: int):
+        """One host-paced sweep of a row shard cut into `n_seg` parts of the order; between two parts every rank
+        publishes what ITS rows changed in the float64 records since the last exchange and takes in the other ranks'
+        changes (distributed.exchange_changes: one all-reduce of 16 bytes per label).  The exact (ordered /
+        one-wavefront) sweeps of a sharded run go through here -- one exchange per sweep does not contract with many
+        shards."""
+        from .distributed import exchange_changes
+        n = int(n_order)
+        if order is None:
+            order = torch.arange(n, dtype=torch.int32, device=self.dev)
+        if getattr(self, "_seg_base", None) is None:
+            self._seg_base = torch.empty_like(self.tpfp)
+            self._seg_buf = torch.empty_like(self.tpfp)
+        self._seg_base.copy_(self.tpfp)
+        bounds = [n * s // n_seg for s in range(n_seg + 1)]
+        total = 0
+        for s in range(n_seg):
+            cnt = bounds[s + 1] - bounds[s]
+            if cnt > 0:
+                self.sweep(order[bounds[s]:bounds[s + 1]], cnt, n_waves)
+                total += int(self.changed.item())
+            if s < n_seg - 1:
+                exchange_changes(self.comm, self.tpfp, self._seg_base, self._seg_buf)
+                if self.shadow is not None:
+                    self.shadow.copy_(self.tpfp)
+        self.changed.fill_(total)
+        self._acc_filled = False
+        self._partial_sweep = True
+        self.orphans = None if n >= self.csr.n else self.orphans
+
     # -- ordered parallel sweep (csrc/xc_bca_ord.hip) ------------------------------------------------------
     def can_sweep_ordered(self, n_order: int, greedy: bool) -> bool:
-        """The reference's sequential semantics with a window of rows in flight: full sweeps of rows of at most 256
-        stored entries (longer rows, greedy first sweeps and partial orders take the one-wavefront sweep).
-        XCOLUMNS_BCA_ORDERED=0 / `ordered=False` disables."""
-        return (self.ordered and not greedy and n_order >= self.csr.n and self.csr.n > 0
-                and int(self.csr.max_row_nnz) <= 256)
+        """The reference's sequential semantics with a window of rows in flight: rows of at most 256 stored entries
+        (longer rows and greedy first sweeps take the one-wavefront sweep).  XCOLUMNS_BCA_ORDERED=0 /
+        `ordered=False` disables."""
+        return (self.ordered and not greedy and n_order > 1 and self.csr.n > 0 and int(self.csr.max_row_nnz) <= 256)
 
     def _ordered_setup(self, orphans: Optional[torch.Tensor]):
         """Label directory of the ordered sweep: which labels get a dense table (a window holds many rows that store
@@ -656,46 +686,8 @@ class BcaCsrEngine:
         self._pack_dirty = True          # sel was rewritten without touching the packed copy
         self._acc_filled = False         # the boundary statistics come from the prediction (a from-scratch pass)
         self._partial_sweep = True       # rows_changed() reads the kernel's counter
-        self.orphans = None
-
-    # -- deterministic concurrent sweep ----------------------------------------------------------------
-    def can_sweep_deterministic(self) -> bool:
-        return self.packed is not None and self.orphans is None
-
-    def sweep_deterministic(self, order: Optional[torch.Tensor], n_order: int, block: int):
-        """One full sweep as blocks of up to `block` rows (xc_bca_det_*): rows of a block are scored on the
-        records as they stood when the block began, changes are settled by integer claims, the boundary
-        statistics are integer sums -- nothing depends on timing.  Leaves the from-scratch statistics in acc."""
-        c = self.csr
-        if self._det_ws is None:
-            nbytes = ctypes.c_int64(0)
-            _lib.call("xc_bca_det_workspace_bytes", int(c.max_row_nnz), c.m, ctypes.byref(nbytes))
-            self._det_ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.dev)
-        if self._pack_dirty:
-            self._repack()
-        block = int(max(2, min(block, 8192)))
-        _lib.call("xc_bca_det_begin", D.ptr(self._det_ws), c.m, D.ptr(self.tpfp), D.stream())
-        progress = (ctypes.c_int64 * 2)(0, 0)
-        iters = (n_order + block - 1) // block + 2
-        stalled = 0
-        while True:
-            before = (progress[0], progress[1])
-            _lib.call("xc_bca_det_blocks", D.ptr(self._det_ws), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
-                      int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta), D.ptr(self.sel), self.k, c.m,
-                      D.ptr(self.packed), ctypes.byref(self.gain_metric), int(self.maximize),
-                      int(self.skip_tn), block, int(iters), progress, D.stream())
-            if progress[0] >= n_order and progress[1] == 0:
-                break
-            # rows that lose a claim take another block: as many more blocks as the rest of the order needs
-            # (the oldest row of a block always wins, so every block settles at least one row)
-            stalled = stalled + 1 if (progress[0], progress[1]) == before else 0
-            if stalled > 64:
-                raise RuntimeError("deterministic sweep makes no progress")
-            iters = max(16, (n_order - int(progress[0]) + block - 1) // block + int(progress[1]) // max(1, block // 4) + 2)
-        _lib.call("xc_bca_det_finish", D.ptr(self._det_ws), c.m, D.ptr(self.acc), D.stream())
-        self._acc_filled = True
-        self._partial_sweep = False
-        self._s_entry_dirty = self._s_entry_dirty   # s_entry is untouched; sel / packed were kept in step
+        if n_order >= c.n:
+            self.orphans = None          # every row was visited: no orphan is left in any prediction
 
     # -- the sweep loop without a host round trip per iteration (include/xcolumns_amd.h) --------
     def can_pipeline(self, n_order: int) -> bool:
@@ -1291,13 +1283,15 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
             D.check_column_ids(init_dev, m, "init_y_pred")
             eng.init_indices(init_dev)
 
+        if bca_deterministic:
+            bca_waves = 1        # every sweep exact: the reference's sequence (ordered parallel sweep where it applies)
         if bca_waves is None and gain_spec.base == _lib.XC_M_PRECISION:
             # Macro precision tp / (tp + fp) jumps when a rarely predicted label gains or loses a row: rows in
             # flight that pick the same attractive label all take it, and the run ends 1e-4 .. 1e-3 BELOW the
             # sequential one even with two wavefronts (tests/studies/fuzz_concurrent.py).  Parity first: the
             # reference's sequential sweep unless the caller sets bca_waves.
-            log_info("  macro precision: using the sequential sweep (bca_waves=1); set bca_waves to trade parity for speed",
-                     verbose)
+            log_info("  macro precision: using the exact sweep (bca_waves=1: the reference's sequence, a window of rows in flight); "
+                     "set bca_waves to trade parity for speed", verbose)
             bca_waves = 1
         # a random / foreign / greedy start changes every row in sweep 1 and keeps many rows moving for several
         # sweeps (measured 5e-5 .. 1.2e-4 at the top-k width): half the budget for the whole run
@@ -1323,6 +1317,7 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
         # updated in place and returned, like the reference does with its matrices (:46, :285-287)
         if isinstance(init_y_pred, D.DeviceCSR):
             init_y_pred.indices.copy_(pred_idx)
+            init_y_pred.forget_cached()      # column sums / ordering cached with the old column ids are stale
             return init_y_pred
         if D.is_torch_sparse_csr(init_y_pred):
             init_y_pred.col_indices().copy_(pred_idx.to(init_y_pred.col_indices().dtype))

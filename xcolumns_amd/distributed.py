@@ -137,6 +137,17 @@ def exchanges_for_sweep(setting, changed_rows: Optional[float], n_total: int, wo
     return int(max(min_exchanges(world), min(EXCHANGES_MAX, want)))
 
 
+def global_policy_inputs(comm: "TorchComm", skewed_local: bool, nnz_local: int, n_total: int, device=None) -> Tuple[bool, float]:
+    """(skewed, mean stored entries per row) over ALL ranks' rows: what a sharded run feeds block_coordinate.WavePolicy,
+    identical on every rank (one MAX and one SUM reduction of a scalar)."""
+    flag = torch.tensor([int(bool(skewed_local))], dtype=torch.int64, device=device)
+    comm.all_reduce_max(flag)
+    nnz = torch.tensor([int(nnz_local)], dtype=torch.int64, device=device)
+    if comm.world > 1:
+        dist.all_reduce(nnz, op=dist.ReduceOp.SUM, group=comm.group)
+    return bool(flag.item()), float(nnz.item()) / max(1, int(n_total))
+
+
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row block of `rank`: sizes differ by at most one row."""
     base, rem = divmod(n, world)
@@ -255,9 +266,13 @@ def predict_bca_csr_sharded(
         return to_dev(local_order(order, lo, hi))
 
     meta = {"utilities": [], "iters": 0, "time": time()}
-    policy = (bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world, k=k, m=m,
-                            row_nnz=y_proba_shard.nnz / max(1, n_local), skewed=eng.skewed)
-              if engine_factory is None else _FixedWaves(bca_waves or 1))
+    if engine_factory is None:
+        # every input of the policy is GLOBAL: a rank that saw a skewed shard (or shorter rows) and chose another sweep
+        # path than its peers would issue other collectives than they do
+        skewed, row_nnz = global_policy_inputs(comm, eng.skewed, y_proba_shard.nnz, n_total, counts_dev)
+        policy = bc.WavePolicy(n_local, fixed=bca_waves, world=comm.world, k=k, m=m, row_nnz=row_nnz, skewed=skewed)
+    else:
+        policy = _FixedWaves(bca_waves or 1)
     bc.run_bca_sweeps(eng, next_order, n_local, n_total, m, metric_aggregation, maximize, tolerance, max_iters,
                       False, policy, verbose, meta)
     if getattr(eng, "exchanges_used", None):

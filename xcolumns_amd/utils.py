@@ -198,6 +198,14 @@ class Pcg64Shuffler:
                         a.shuffle(ref)
                         cls._walk(b, mine)
                     ok = ok and np.array_equal(ref, mine) and a.integers(0, 1 << 62, size=4).tolist() == b.integers(0, 1 << 62, size=4).tolist()
+                    # the two-thread form the sweep loop uses by default (draws(), then apply()) against numpy as well
+                    c = np.random.default_rng(seed)
+                    ref2, two = np.arange(n), cls(np.random.default_rng(seed), n)
+                    for _ in range(3):
+                        c.shuffle(ref2)
+                        two.apply(two.draws())
+                    ok = ok and np.array_equal(ref2, two.order) and (c.integers(0, 1 << 62, size=4).tolist()
+                                                                     == two.rng.integers(0, 1 << 62, size=4).tolist())
                 cls._ok = bool(ok)
             except Exception:
                 cls._ok = False
