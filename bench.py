@@ -527,6 +527,7 @@ def worker(args):
         # (2) BASELINE.md section 4's quantity: ONE public call, fixed number of sweeps
         try:
             out["api_call"] = api_call_leg(Y, args.steps)
+            out["roofline"]["frac_api_call"] = out["api_call"]["device_resident"]["roofline_frac"]
         except Exception as e:
             out["api_call"] = {"error": repr(e)}
         # (3) the same workload with Zipf(1) label popularity (real XMLC data is long-tailed)
@@ -584,38 +585,47 @@ def worker(args):
 
 def api_call_leg(Y, sweeps):
     """rows/s of ONE predict_optimizing_macro_f1_score_using_bc(y_proba, k, tolerance < 0, max_iters = K) call:
-    BASELINE.md section 4's definition of the metric (wall time of the call; the reference's numpy visiting
-    order, the drop-in default).  From a scipy matrix in host memory (upload over PCIe included) and from a
-    matrix already resident in HBM (xcolumns_amd.DeviceCSR)."""
+    BASELINE.md section 4's definition of the metric (wall time of the call).  From a scipy matrix in host memory
+    (upload over PCIe included) and from a matrix already resident in HBM (xcolumns_amd.DeviceCSR), at K, 10 and 20
+    sweeps; visiting orders: the reference's numpy stream generated on the GPU (the drop-in default,
+    csrc/xc_order_dev.hip), the same stream walked on the host (two worker threads, XCOLUMNS_ORDER_DEVICE=0) and
+    torch.randperm (order_backend="device": another stream, what the loop costs without numpy's sequential walk)."""
     import torch
 
     from xcolumns_amd import _device as D
     from xcolumns_amd.block_coordinate import predict_optimizing_macro_f1_score_using_bc as f
 
     n = Y.shape[0]
-    res = {"sweeps": sweeps, "order": "numpy default_rng stream (drop-in default)"}
-    for name, inp in (("host_csr_matrix", Y), ("device_resident", D.DeviceCSR.from_scipy(Y))):
+
+    def timed(inp, k_sweeps, reps=5, **kw):
         times = []
-        for _ in range(6):      # the first call also starts the order workers and warms the allocator: not reported
+        for _ in range(reps + 1):      # the first call warms the allocator / starts the order machinery: not reported
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            _, meta = f(inp, K, tolerance=-1.0, max_iters=sweeps, seed=ORDER_SEED, return_meta=True)
+            _, meta = f(inp, K, tolerance=-1.0, max_iters=k_sweeps, seed=ORDER_SEED, return_meta=True, **kw)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-        assert meta["iters"] == sweeps
-        if os.environ.get("XC_BENCH_API_PROFILE") == "1":      # where the host side of one call spends its time
-            import cProfile
-            import pstats
-            pr = cProfile.Profile()
-            pr.enable()
-            f(inp, K, tolerance=-1.0, max_iters=sweeps, seed=ORDER_SEED, return_meta=True)
-            torch.cuda.synchronize()
-            pr.disable()
-            print(name, ["%.1f" % (t * 1e3) for t in times], file=sys.stderr)
-            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
+        assert meta["iters"] == k_sweeps
         med = float(np.median(times[1:]))
-        res[name] = {"ms": med * 1e3, "rows_per_s": n * sweeps / med, "ms_min": min(times[1:]) * 1e3,
-                     "ms_max": max(times[1:]) * 1e3, "calls": len(times) - 1}
+        return {"ms": med * 1e3, "rows_per_s": n * k_sweeps / med, "ms_min": min(times[1:]) * 1e3,
+                "ms_max": max(times[1:]) * 1e3, "calls": reps,
+                "roofline_frac": algorithmic_bytes_per_row_sweep(R_NNZ, K) * n * k_sweeps / med / 1e9 / HBM_PEAK_GBS}
+
+    res = {"sweeps": sweeps, "order": "numpy default_rng stream, generated on the GPU (drop-in default)"}
+    Yd = D.DeviceCSR.from_scipy(Y)
+    res["host_csr_matrix"] = timed(Y, sweeps, reps=3)
+    res["device_resident"] = timed(Yd, sweeps)
+    by = {}
+    for k_sweeps in sorted({10, 20}):
+        row = {"numpy_stream_on_gpu": timed(Yd, k_sweeps)}
+        os.environ["XCOLUMNS_ORDER_DEVICE"] = "0"
+        try:
+            row["numpy_stream_on_host_threads"] = timed(Yd, k_sweeps, reps=3)
+        finally:
+            os.environ.pop("XCOLUMNS_ORDER_DEVICE", None)
+        row["torch_randperm"] = timed(Yd, k_sweeps, reps=3, order_backend="device")
+        by[str(k_sweeps)] = row
+    res["device_resident_by_sweeps"] = by
     return res
 
 

@@ -601,6 +601,27 @@ int xc_coverage_product(int64_t n_k, const int32_t *pred_indices, const void *pr
                         double *ef, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The visiting order generated ON the GPU (csrc/xc_order_dev.hip): numpy's `Generator.shuffle` stream -- the
+ * reference's `np.random.default_rng(seed)`, one array shuffled cumulatively once per sweep
+ * (block_coordinate.py:413-419) -- with no host arithmetic and no host synchronisation per sweep: the PCG64
+ * outputs by jump-ahead, the masked rejection by one wavefront, the Fisher-Yates swaps resolved in parallel.
+ * Same permutation and same generator position as numpy (the wrapper checks both against numpy at first use).
+ * ------------------------------------------------------------------------- */
+
+/* 32-bit candidates a shuffle of n entries may draw (expectation of the masked rejection + 8 sigma). */
+int xc_order_dev_candidates(int64_t n, int64_t *count);
+int xc_order_dev_workspace_bytes(int64_t n, int64_t *bytes);
+/* state_inc = {state_hi, state_lo, inc_hi, inc_lo} of rng.bit_generator.state["state"]: the NEXT 64-bit output is the
+ * XSL-RR of the state stepped once.  consumed = 0, or 1 when the generator holds a buffered 32-bit half (pass the
+ * state stepped BACK once then).  order (int32[n], device) <- 0 .. n - 1. */
+int xc_order_dev_begin(void *workspace, const uint64_t *state_inc, int consumed, int64_t n, int32_t *order, void *stream);
+/* order_out <- one Generator.shuffle of order_in (int32[n] each, device, distinct); asynchronous on `stream`. */
+int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, int32_t *order_out, void *stream);
+/* out7_host = {failure flag (0: every shuffle so far is numpy's), 32-bit draws consumed, shuffles, shader cycles and
+ * 100 MHz ticks of the last rejection walk, its rounds and batches}; blocks on `stream`. */
+int xc_order_dev_status(void *workspace, int64_t *out7_host, void *stream);
+
+/* ---------------------------------------------------------------------------
  * The ORDERED parallel sweep (csrc/xc_bca_ord.hip): the loop of block_coordinate.py:448-463 with thousands of
  * rows in flight AND its sequential semantics -- every row decides on the statistics as the rows BEFORE it in
  * the visiting order left them.  Replaces the one-wavefront sweep wherever the reference's own trajectory is

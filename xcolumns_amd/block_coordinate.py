@@ -922,7 +922,11 @@ class _OrderSource:
     """Visiting order per sweep (block_coordinate.py:413-419): the reference's stream --
     ``np.random.default_rng(seed)``, ONE array shuffled cumulatively, once per iteration.
 
-    The shuffle is sequential host work (numpy: 8 ms for 1 M rows, 12x the sweep it feeds).  For large matrices it is
+    Large matrices (>= 50 K rows): the stream is generated ON the GPU (utils.DeviceNumpyOrders, csrc/xc_order_dev.hip:
+    PCG64 outputs by jump-ahead, the masked rejection by one wavefront, the Fisher-Yates swaps resolved in parallel) --
+    the same permutations, no host work per sweep; XCOLUMNS_ORDER_DEVICE=0 selects the host walk below.
+
+    On the host the shuffle is sequential work (numpy: 8 ms for 1 M rows, 12x the sweep it feeds).  There it is
     (a) done by the library's own walk of numpy's stream (utils.Pcg64Shuffler: same permutation, 2.3 ms of draws +
     0.8 ms of swaps) and (b) taken off the critical path: the draws of sweep j + 2 and the swaps + upload of sweep
     j + 1 run on two persistent worker threads (:class:`_OrderWorkers`; the C routines release the GIL) while sweep j
@@ -945,12 +949,21 @@ class _OrderSource:
             from .utils import Pcg64Shuffler
             if Pcg64Shuffler.usable():
                 self._fast = Pcg64Shuffler(self.rng, n)
+        # numpy's stream generated ON the GPU (csrc/xc_order_dev.hip, utils.DeviceNumpyOrders): no host work per sweep
+        self._devgen = None
+        if (backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS
+                and os.environ.get("XCOLUMNS_ORDER_DEVICE", "1") != "0"):
+            from .utils import DeviceNumpyOrders
+            if DeviceNumpyOrders.usable(dev):
+                self._devgen = DeviceNumpyOrders(self.rng, n, dev)
+                self._fast = None
         if backend == "device" and shuffle:
             self.gen = torch.Generator(device=dev)
             self.gen.manual_seed(int(seed) if seed is not None else int(self.rng.integers(2 ** 31)))
         if prefetch is None:
             prefetch = os.environ.get("XCOLUMNS_ORDER_PREFETCH", "1") != "0"
-        if backend == "numpy" and shuffle and prefetch and n >= _ORDER_PREFETCH_ROWS and _OrderWorkers.acquire():
+        if (self._devgen is None and backend == "numpy" and shuffle and prefetch and n >= _ORDER_PREFETCH_ROWS
+                and _OrderWorkers.acquire()):
             import queue
             import threading
             self._threaded = True
@@ -1062,6 +1075,8 @@ class _OrderSource:
     def next(self) -> Optional[torch.Tensor]:
         if not self.shuffle:
             return None
+        if self._devgen is not None:
+            return self._devgen.next()
         if self._threaded:
             item = self._get(self._q)
             if item is None:
@@ -1079,6 +1094,9 @@ class _OrderSource:
 
     def close(self):
         """Stop the workers' jobs (orders generated ahead of an early stop are dropped) and hand the workers back."""
+        if self._devgen is not None:
+            gen, self._devgen = self._devgen, None
+            gen.finish()       # raises if a shuffle on the device failed; leaves the generator where numpy would
         if self._threaded:
             self._stop.set()
             deadline = _time.monotonic() + 10.0

@@ -249,3 +249,179 @@ class Pcg64Shuffler:
         from . import _lib
         _lib.call("xc_host_shuffle_apply", self.n, ctypes.c_void_p(js.ctypes.data), ctypes.c_void_p(self.order.ctypes.data))
         return self.order
+
+
+# ---------------------------------------------------------------------------
+# ... and the same stream generated on the GPU
+# ---------------------------------------------------------------------------
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_PCG64_MULT = (2549297995355413924 << 64) | 4865540595714422341
+_MASK128 = (1 << 128) - 1
+
+
+def pcg64_advance(state: int, inc: int, steps: int) -> int:
+    """The PCG64 state `steps` steps further (steps < 0: back), by the LCG's jump-ahead."""
+    steps %= 1 << 128
+    acc_mult, acc_plus, cur_mult, cur_plus = 1, 0, _PCG64_MULT, inc
+    while steps:
+        if steps & 1:
+            acc_mult = (acc_mult * cur_mult) & _MASK128
+            acc_plus = (acc_plus * cur_mult + cur_plus) & _MASK128
+        cur_plus = ((cur_mult + 1) * cur_plus) & _MASK128
+        cur_mult = (cur_mult * cur_mult) & _MASK128
+        steps >>= 1
+    return (acc_mult * state + acc_plus) & _MASK128
+
+
+class DeviceNumpyOrders:
+    """``rng.shuffle(order)`` of a ``np.random.default_rng`` generator, cumulatively, ON the GPU
+    (csrc/xc_order_dev.hip): :meth:`next` returns the int32 order tensor of the next sweep -- the permutation numpy
+    would produce -- with no host work per sweep.  The orders are generated `ahead` shuffles in advance on a side
+    stream (the masked rejection is one wavefront's work: it runs beside the sweeps); the consumer's stream waits for
+    the order it is handed.  :meth:`finish` raises if a shuffle failed (candidate buffer exhausted: sized for 8
+    standard deviations) and, with ``sync_rng`` (and ``ahead=0``), leaves the Python generator where numpy's own
+    shuffles would have."""
+
+    _ok = None
+    DEPTH = 4     # order buffers in rotation
+
+    def __init__(self, rng: np.random.Generator, n: int, device, ahead: int = 2):
+        import ctypes
+
+        import torch
+
+        from . import _device as D
+        from . import _lib
+        self.rng, self.n, self.dev = rng, int(n), device
+        self.ahead = int(max(0, min(ahead, self.DEPTH - 2)))
+        st = rng.bit_generator.state
+        if st["bit_generator"] != "PCG64":
+            raise ValueError("DeviceNumpyOrders needs a PCG64 generator (np.random.default_rng)")
+        self._state0, self._inc = int(st["state"]["state"]), int(st["state"]["inc"])
+        has = int(st["has_uint32"])
+        base = pcg64_advance(self._state0, self._inc, -1) if has else self._state0
+        self._base, self._has0 = base, has
+        nbytes = ctypes.c_int64(0)
+        _lib.call("xc_order_dev_workspace_bytes", self.n, ctypes.byref(nbytes))
+        self.ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=device)
+        self.bufs = [torch.empty(max(1, self.n), dtype=torch.int32, device=device) for _ in range(self.DEPTH)]
+        self.side = torch.cuda.Stream(device=device) if self.ahead > 0 else None
+        mask = (1 << 64) - 1
+        words = (ctypes.c_uint64 * 4)(base >> 64, base & mask, self._inc >> 64, self._inc & mask)
+        with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
+            _lib.call("xc_order_dev_begin", D.ptr(self.ws), ctypes.cast(words, ctypes.c_void_p), has, self.n,
+                      D.ptr(self.bufs[0]), D.stream())
+        self.generated = 0          # shuffles enqueued
+        self.handed = 0             # orders handed to the consumer
+        self._done = {}             # shuffle number -> event on the side stream
+        self._free = {}             # order number -> event on the consumer's stream recorded when the NEXT order was handed out
+        for _ in range(self.ahead):
+            self._generate()
+
+    def _generate(self):
+        """Enqueue shuffle number generated + 1: bufs[k % DEPTH] <- shuffle of bufs[(k - 1) % DEPTH]."""
+        import torch
+
+        from . import _device as D
+        from . import _lib
+        k = self.generated + 1
+        with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
+            if self.side is not None:
+                # the buffer held order k - DEPTH: its sweep was enqueued before order k - DEPTH + 1 was handed out
+                ev = self._free.pop(k - self.DEPTH + 1, None)
+                if ev is not None:
+                    self.side.wait_event(ev)
+            _lib.call("xc_order_dev_shuffle", D.ptr(self.ws), self.n, D.ptr(self.bufs[(k - 1) % self.DEPTH]),
+                      D.ptr(self.bufs[k % self.DEPTH]), D.stream())
+            if self.side is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self._done[k] = ev
+        self.generated = k
+
+    def next(self):
+        import torch
+        k = self.handed + 1
+        cur = torch.cuda.current_stream()
+        if self.side is not None:
+            # whatever the consumer enqueued so far (the sweeps of the orders handed out before) precedes this point
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._free[k] = ev
+        while self.generated < k + self.ahead:
+            self._generate()
+        if self.side is not None:
+            cur.wait_event(self._done.pop(k))
+        self.handed = k
+        return self.bufs[k % self.DEPTH][:self.n]
+
+    def status(self):
+        import ctypes
+
+        import torch
+
+        from . import _device as D
+        from . import _lib
+        out = (ctypes.c_int64 * 8)()
+        with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
+            _lib.call("xc_order_dev_status", D.ptr(self.ws), out, D.stream())
+        self.last_walk = {"cycles": int(out[3]), "us": int(out[4]) / 100.0, "rounds": int(out[5]), "batches": int(out[6])}
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def finish(self, sync_rng: bool = False) -> None:
+        flag, consumed, _ = self.status()
+        if flag != 0:
+            raise RuntimeError(f"the device visiting-order generator failed (flag {flag}); set XCOLUMNS_ORDER_DEVICE=0")
+        if not sync_rng:
+            return
+        if self.generated != self.handed:
+            raise ValueError("sync_rng needs ahead=0 (orders generated in advance moved the generator further)")
+        st = self.rng.bit_generator.state
+        # draw d is the low / high half of output d // 2 (counted from the base state): after `consumed` draws the
+        # generator has made ceil(consumed / 2) outputs and, if consumed is odd, still holds the high half of the last
+        outputs = (consumed + 1) // 2
+        state = pcg64_advance(self._base, self._inc, outputs)
+        st["state"]["state"] = state
+        st["has_uint32"] = consumed & 1
+        if consumed & 1:
+            hi, lo = state >> 64, state & ((1 << 64) - 1)
+            x, rot = hi ^ lo, hi >> 58
+            out = ((x >> rot) | (x << ((64 - rot) & 63))) & ((1 << 64) - 1)
+            st["uinteger"] = out >> 32
+        self.rng.bit_generator.state = st
+
+    @classmethod
+    def usable(cls, device) -> bool:
+        """Checked against numpy once per process: permutations of three cumulative shuffles at sizes around the
+        mask boundaries, and the generator's next draws afterwards."""
+        if cls._ok is None:
+            try:
+                ok = True
+                for seed, n in ((13, 2), (7, 3), (3, 64), (5, 65), (123, 1000), (9, 4097), (11, 70001)):
+                    a, b = np.random.default_rng(seed), np.random.default_rng(seed)
+                    if seed == 9:
+                        a.integers(0, 10, size=3, dtype=np.uint32)      # leave a buffered 32-bit half behind
+                        b.integers(0, 10, size=3, dtype=np.uint32)
+                    ref = np.arange(n)
+                    gen = cls(b, n, device, ahead=0 if seed != 11 else 2)
+                    for _ in range(3):
+                        a.shuffle(ref)
+                        mine = gen.next().cpu().numpy()
+                        ok = ok and np.array_equal(ref, mine)
+                    if seed == 11:
+                        gen.finish()
+                        continue
+                    gen.finish(sync_rng=True)
+                    ok = ok and a.integers(0, 1 << 62, size=4).tolist() == b.integers(0, 1 << 62, size=4).tolist()
+                cls._ok = bool(ok)
+            except Exception:
+                cls._ok = False
+        return cls._ok
