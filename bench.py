@@ -611,18 +611,22 @@ def api_call_leg(Y, sweeps):
                 "ms_max": max(times[1:]) * 1e3, "calls": reps,
                 "roofline_frac": algorithmic_bytes_per_row_sweep(R_NNZ, K) * n * k_sweeps / med / 1e9 / HBM_PEAK_GBS}
 
-    res = {"sweeps": sweeps, "order": "numpy default_rng stream, generated on the GPU (drop-in default)"}
+    res = {"sweeps": sweeps, "order": "numpy default_rng stream (drop-in default): generated on the GPU or walked by two host threads, "
+                                      "whichever is faster on the machine (block_coordinate._orders_on_device)"}
     Yd = D.DeviceCSR.from_scipy(Y)
     res["host_csr_matrix"] = timed(Y, sweeps, reps=3)
     res["device_resident"] = timed(Yd, sweeps)
     by = {}
+    from xcolumns_amd.block_coordinate import _orders_on_device
+    res["order_default_on_this_machine"] = "gpu" if _orders_on_device() else "host threads"
     for k_sweeps in sorted({10, 20}):
-        row = {"numpy_stream_on_gpu": timed(Yd, k_sweeps)}
-        os.environ["XCOLUMNS_ORDER_DEVICE"] = "0"
-        try:
-            row["numpy_stream_on_host_threads"] = timed(Yd, k_sweeps, reps=3)
-        finally:
-            os.environ.pop("XCOLUMNS_ORDER_DEVICE", None)
+        row = {"default": timed(Yd, k_sweeps)}
+        for name, flag in (("numpy_stream_on_gpu", "1"), ("numpy_stream_on_host_threads", "0")):
+            os.environ["XCOLUMNS_ORDER_DEVICE"] = flag
+            try:
+                row[name] = timed(Yd, k_sweeps, reps=3)
+            finally:
+                os.environ.pop("XCOLUMNS_ORDER_DEVICE", None)
         row["torch_randperm"] = timed(Yd, k_sweeps, reps=3, order_backend="device")
         by[str(k_sweeps)] = row
     res["device_resident_by_sweeps"] = by

@@ -161,20 +161,6 @@ int xc_confusion_csr(int64_t n, int64_t m, const int32_t *t_indptr,
                      const void *p_data, int dtype, double *tp, double *fp,
                      double *fn, void *stream);
 
-/* The same statistics for LARGE inputs without one global atomic per contribution (the memory side retires
- * ~23.5 G scattered float64 adds per second): the contributions are counting-sorted into buckets of consecutive
- * labels and summed in LDS (csrc/xc_confusion.hip, "bucketed form").  Same arguments and the same
- * accumulate-into contract as xc_confusion_csr, plus the stored-entry counts of the two matrices
- * (t_indptr[n], p_indptr[n], known to the host) and a workspace of xc_confusion_csr_workspace_bytes bytes.
- * Limits: m <= 2^25, 2 nnz_pred + nnz_true < 2^31 (XC_ERR_BAD_ARG beyond: use xc_confusion_csr). */
-int xc_confusion_csr_workspace_bytes(int64_t n, int64_t m, int64_t nnz_true, int64_t nnz_pred, int dtype,
-                                     int64_t *bytes);
-int xc_confusion_csr_bucketed(int64_t n, int64_t m, const int32_t *t_indptr,
-                              const int32_t *t_indices, const void *t_data,
-                              const int32_t *p_indptr, const int32_t *p_indices,
-                              const void *p_data, int dtype, int64_t nnz_true, int64_t nnz_pred,
-                              double *tp, double *fp, double *fn, void *workspace, void *stream);
-
 /* The same statistics with atomics for the PREDICTED entries only, given the column sums of y_true:
  *   fn[j] = colsum_t[j] - sum over the entries of y_true that meet a predicted one of [t - (T)(t (1 - p))].
  * The caller puts colsum_t (float64 sums of y_true's columns; it depends on y_true alone and can be kept) into fn and

@@ -330,7 +330,7 @@ def test_sharded_bca_eight_ranks_default_exchanges_meet_the_bar(oref):
     _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=6, tolerance=-1.0)
     d = np.abs(np.asarray(u0) - np.asarray(mo["utilities"]))
     print("8 shards, exchanges", ex0, "|utility - sequential oracle| per sweep:", d)
-    assert d[-1] < 1e-5, d
+    assert d[0] < 5e-5 and d[1:].max() < 1e-5, d          # the first sweep within 5e-5, every later one within north_star's 1e-5
     assert ex0[0] == EXCHANGES_MAX and min(ex0) >= min_exchanges(8) == 4
     assert (np.diff(u0) > -1e-6).all()                 # the iteration contracts: the utility never falls
     # the assembled prediction is what the last utility describes

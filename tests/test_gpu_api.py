@@ -87,18 +87,22 @@ def test_device_resident_inputs_bca(oref):
         DeviceCSR.from_parts(d.indptr, d.indices + m, d.data, d.shape)   # column ids out of range
 
 
-def test_order_worker_delivers_the_reference_stream():
-    """The visiting orders a worker thread prepares ahead (pinned buffer, side stream) are numpy's stream."""
+@pytest.mark.parametrize("where", ["gpu", "host_threads"])
+def test_order_source_delivers_the_reference_stream(where, monkeypatch):
+    """The visiting orders prepared ahead -- generated on the GPU (the default for large matrices), or walked by the
+    host's worker threads into a pinned buffer and copied on a side stream (XCOLUMNS_ORDER_DEVICE=0) -- are numpy's."""
     from xcolumns_amd import _device as D
     from xcolumns_amd.block_coordinate import _OrderSource
 
+    # (unset, the faster of the two on this machine is taken: block_coordinate._orders_on_device)
+    monkeypatch.setenv("XCOLUMNS_ORDER_DEVICE", "0" if where == "host_threads" else "1")
     n = 120_000
     dev = D.require_gpu()
     src = _OrderSource(n, 13, True, "numpy", dev)
-    assert src._threaded
     rng = np.random.default_rng(13)
     ref = np.arange(n)
     try:
+        assert src._threaded == (where == "host_threads") and (src._devgen is not None) == (where == "gpu")
         for _ in range(6):
             rng.shuffle(ref)
             got = src.next()
@@ -106,7 +110,7 @@ def test_order_worker_delivers_the_reference_stream():
             assert got.dtype == torch.int32 and got.is_cuda and np.array_equal(got.cpu().numpy(), ref.astype(np.int32))
     finally:
         src.close()
-    assert not src._threaded
+    assert not src._threaded and src._devgen is None
 
 
 def test_rccl_all_reduce_through_torchcomm():

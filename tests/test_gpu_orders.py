@@ -46,13 +46,10 @@ def test_device_orders_with_a_buffered_half_and_many_sweeps():
     gen.finish(sync_rng=True)
     assert a.random(3).tolist() == b.random(3).tolist()
     # generated ahead on a side stream (the product's form): the same orders, a consumer that keeps reading them
-    c = np.random.default_rng(5)
-    c.integers(0, 1000, size=7, dtype=np.uint32)
-    ref2, gen2 = np.arange(n), DeviceNumpyOrders(np.random.default_rng(5), n, dev, ahead=2)
-    gen2b = None
-    r = np.random.default_rng(5)
-    r.integers(0, 1000, size=7, dtype=np.uint32)
-    gen2 = DeviceNumpyOrders(r, n, dev, ahead=2)
+    c, r = np.random.default_rng(5), np.random.default_rng(5)
+    for g in (c, r):
+        g.integers(0, 1000, size=7, dtype=np.uint32)
+    ref2, gen2 = np.arange(n), DeviceNumpyOrders(r, n, dev, ahead=2)
     sums = []
     for s in range(12):
         c.shuffle(ref2)
@@ -61,7 +58,13 @@ def test_device_orders_with_a_buffered_half_and_many_sweeps():
         if s in (0, 5, 11):
             assert np.array_equal(ref2, o.cpu().numpy()), s
     gen2.finish()
-    assert gen2b is None
+    # a generator dropped without finish() while its side stream still works must not hand its buffers to anybody else
+    for _ in range(3):
+        g3 = DeviceNumpyOrders(np.random.default_rng(1), n, dev, ahead=2)
+        g3.next()
+        del g3
+        torch.empty(n, dtype=torch.int32, device=dev).zero_()
+    torch.cuda.synchronize()
 
 
 def test_device_orders_time_and_api_use(oref):

@@ -58,10 +58,6 @@ SIGNATURES = {
                               c_void_p, c_int, c_void_p]),
     "xc_confusion_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "xc_confusion_csr_workspace_bytes": (c_int, [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(c_int64)]),
-    "xc_confusion_csr_bucketed": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p]),
     "xc_csr_rows_ascending": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_confusion_csr_pred_side": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

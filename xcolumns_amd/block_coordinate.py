@@ -92,8 +92,11 @@ from .weighted_prediction import topk_csr_device, topk_dense_device
 #     (intermediate sweeps of a top-k start stay within ~5e-5), for callers that only use the result.
 # A changing row moves more labels the larger k is and the trajectories then settle in different, nearly
 # equivalent optima (k = 64, n = 6000, m = 900: 1.6e-4 in sweep 1 at the k = 5 width, 1.3e-5 with (5 / k)^1.5), hence (5 / k)^2.
-_BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.05"))
-_SKEWED_FIRST_SWEEP = 0.0616
+# round 3: 0.05 -> 0.025.  Over five visiting orders the worst sweep sat at 0.95 / 0.97 of the bar on 100 K x 30 K / 200 K x 60 K
+# with 0.05, at 0.34 / 0.30 with 0.025, and no lower with 0.0125 (0.47 / 0.31: the floor of this chaotic quantity) --
+# tests/studies/beta_margin_study.py, profiles/r03_beta_margin_study.txt; the tests hold 0.5 of the bar (tests/_parity.py)
+_BETA = float(os.environ.get("XCOLUMNS_BCA_BETA", "0.025"))
+_SKEWED_FIRST_SWEEP = 0.1232   # x 2 with _BETA / 2 in round 3: the skewed first sweep keeps the width measured in round 2 (976 wavefronts at 1 M x 500 K)
 _FINAL_PARITY_FACTOR = 4.0
 _STALE_BUDGET = float(os.environ["XCOLUMNS_BCA_STALE_BUDGET"]) if "XCOLUMNS_BCA_STALE_BUDGET" in os.environ else None
 _MIN_WAVES = 1
@@ -195,7 +198,12 @@ class WavePolicy:
             # skewed popularity: every row changes in sweep 1, mostly into tail labels that hold one or two rows --
             # a single decision that falls the other way moves such a label's F1 by ~0.3, i.e. the utility by
             # 0.3 / m: on a 30 K-label space three of them are the whole 1e-5
-            self.first_factor = _SKEWED_FIRST_SWEEP * min(1.0, float(m) / 200000.0) if skewed else 1.0
+            # (uniform popularity, round 3: HALF the width for the first sweep.  At 1 M x 500 K the whole GPU -- 7924 wavefronts
+            # -- put sweep 1 at 0.78 / 0.53 of the bar on two of five visiting orders, reproducibly per order; the
+            # difference falls in proportion to the width (0.29 at 2535, 0.13 at 1267 wavefronts), later sweeps sit below
+            # 0.2, and the sweep kernel is throughput-bound from ~2500 wavefronts on, so the narrower first sweep costs
+            # little: tests/studies/ns_first_sweep_margin.py, profiles/r03_ns_first_sweep_margin.txt)
+            self.first_factor = _SKEWED_FIRST_SWEEP * min(1.0, float(m) / 200000.0) if skewed else 0.5
             if skewed and self.parity == "final" and (sweeps is None or int(sweeps) >= 2):
                 # what a wide first sweep leaves behind on skewed labels heals in the next one: 100 K x 30 K Zipf at 8192
                 # wavefronts 1.9-3.6e-4 after sweep 1, 2.9-4.3e-6 after sweep 2, <= 3e-7 from sweep 3 on (three visiting
@@ -918,6 +926,42 @@ class _OrderWorkers:
         return done
 
 
+_DEVICE_WALK_NS_PER_ROW = 2.7     # csrc/xc_order_dev.hip: per row and sweep of a 20-sweep call at 1 M rows, measured (profiles/r03_api_call_timing.txt)
+_order_choice = None
+
+
+def _orders_on_device() -> bool:
+    """Where numpy's visiting-order stream is generated for large matrices: XCOLUMNS_ORDER_DEVICE=1 / 0 forces the GPU
+    / the host's two worker threads; by default whichever is faster on THIS machine -- the device generator takes the
+    same 2.7 ns per row everywhere, the host's sequential walk 1.3 ns per row on a fast idle core (then the call is
+    nearly kernel-bound) and 4 ns and more on a slow or busy one (measured once per process on 256 K rows)."""
+    global _order_choice
+    env = os.environ.get("XCOLUMNS_ORDER_DEVICE")
+    if env is not None:
+        return env != "0"
+    if _order_choice is None:
+        choice = True
+        try:
+            from .utils import Pcg64Shuffler
+            if Pcg64Shuffler.usable():
+                sh = Pcg64Shuffler(np.random.default_rng(0), 1 << 18)
+                sh.apply(sh.draws())                       # first touch of the buffers
+                t0 = _time.perf_counter()
+                for _ in range(3):
+                    js = sh.draws()
+                draws = (_time.perf_counter() - t0) / 3    # the two halves run on two threads: the slower one paces
+                t0 = _time.perf_counter()
+                for _ in range(3):
+                    sh.apply(js)
+                swaps = (_time.perf_counter() - t0) / 3
+                host_ns = max(draws, swaps) / (1 << 18) * 1e9
+                choice = host_ns > 0.9 * _DEVICE_WALK_NS_PER_ROW
+        except Exception:
+            choice = True
+        _order_choice = choice
+    return _order_choice
+
+
 class _OrderSource:
     """Visiting order per sweep (block_coordinate.py:413-419): the reference's stream --
     ``np.random.default_rng(seed)``, ONE array shuffled cumulatively, once per iteration.
@@ -951,8 +995,7 @@ class _OrderSource:
                 self._fast = Pcg64Shuffler(self.rng, n)
         # numpy's stream generated ON the GPU (csrc/xc_order_dev.hip, utils.DeviceNumpyOrders): no host work per sweep
         self._devgen = None
-        if (backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS
-                and os.environ.get("XCOLUMNS_ORDER_DEVICE", "1") != "0"):
+        if backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS and _orders_on_device():
             from .utils import DeviceNumpyOrders
             if DeviceNumpyOrders.usable(dev):
                 self._devgen = DeviceNumpyOrders(self.rng, n, dev)

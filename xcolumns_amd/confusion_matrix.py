@@ -101,11 +101,6 @@ class ConfusionMatrix:
 # device-level
 # ---------------------------------------------------------------------------
 
-# Measured on MI355X (profiles/r02_confusion_timing.txt): the bucketed form is NOT faster yet -- 2.9 ms against 2.4 ms
-# at 1 M x 500 K x 50 (its two row passes cost 0.8 ms each before any sorting), 3.0 against 1.85 ms at the C5 shape --
-# so nothing selects it by default; XCOLUMNS_CONFUSION_BUCKETED=1 forces it (tests keep it pinned to the same goldens).
-_BUCKETED_MIN_ITEMS = None
-_BUCKETED_MAX_LABELS = 16384 * 2048   # XC_CF_BUCKETS_MAX x XC_CF_BUCKET_LABELS_MAX
 _PRED_SIDE_MIN_ITEMS = 1_000_000      # below this the general kernel's single pass is as fast
 
 
@@ -113,26 +108,14 @@ def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR, keeps: bool = True) -> 
     """tp | fp | fn as a (3, m) float64 tensor on the GPU.  `keeps`: `t` is an object the caller holds on to (a
     DeviceCSR of theirs), so what is derived from it alone -- column sums, the row check -- pays off on later calls."""
     out = torch.zeros((3, t.m), dtype=torch.float64, device=t.data.device)
-    # many contributions: counting-sort them by label bucket and sum in LDS instead of one global atomic each
-    # (xc_confusion_csr_bucketed; the memory side retires ~23.5 G scattered adds/s).  XCOLUMNS_CONFUSION_BUCKETED=0/1 forces.
     items = 2 * p.nnz + t.nnz
-    forced = os.environ.get("XCOLUMNS_CONFUSION_BUCKETED")
-    fits = items < 2 ** 31 and t.m <= _BUCKETED_MAX_LABELS and t.n > 0
-    if fits and (forced == "1" or (forced is None and _BUCKETED_MIN_ITEMS is not None and items >= _BUCKETED_MIN_ITEMS)):
-        nbytes = ctypes.c_int64(0)
-        _lib.call("xc_confusion_csr_workspace_bytes", t.n, t.m, t.nnz, p.nnz, t.code, ctypes.byref(nbytes))
-        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=t.data.device)
-        _lib.call("xc_confusion_csr_bucketed", t.n, t.m, D.ptr(t.indptr), D.ptr(t.indices), D.ptr(t.data),
-                  D.ptr(p.indptr), D.ptr(p.indices), D.ptr(p.data), t.code, t.nnz, p.nnz, D.ptr(out[0]), D.ptr(out[1]),
-                  D.ptr(out[2]), D.ptr(ws), D.stream())
-        return out
     # Atomics for the PREDICTED entries only (xc_confusion_csr_pred_side): fn starts from the column sums of y_true --
     # kept with the matrix, so a second prediction scored against the same y_true pays nnz(y_pred) + 2 matches
     # atomics instead of nnz(y_pred) + nnz(y_true) (1 M x 500 K x 50, k = 5: 2.4 -> 0.7 ms; the first call also
     # sums the columns and checks the rows once).  A y_pred row that is not strictly ascending -- the reference's top-k
     # pads a short row with column 0 -- or a y_true that is not falls back to the general kernel.
     # XCOLUMNS_CONFUSION_PRED_SIDE=0 disables.
-    if (keeps and forced is None and os.environ.get("XCOLUMNS_CONFUSION_PRED_SIDE", "1") != "0" and t.n > 0
+    if (keeps and os.environ.get("XCOLUMNS_CONFUSION_PRED_SIDE", "1") != "0" and t.n > 0
             and items >= _PRED_SIDE_MIN_ITEMS and t.nnz > 2 * p.nnz and t.rows_ascending()):
         out[2].copy_(t.column_sums())
         flag = torch.zeros(1, dtype=torch.int32, device=t.data.device)

@@ -7,10 +7,11 @@
 //            three passes there, ONE fused pass here;
 //   dense -> np.sum(y_true * y_pred, axis=0, dtype=float64) etc.
 //            (confusion_matrix.py:160-166, :187-202).
-// Column accumulation: float64 global atomics (global_atomic_add_f64) for small inputs; for large ones
-// (xc_confusion_csr_bucketed) the (label, statistic, value) contributions are counting-sorted into buckets of
-// consecutive labels and summed in LDS, one workgroup per bucket -- the memory side retires ~23.5 G scattered
-// atomic adds per second whatever their scope (tools/atomic_scope_probe.hip), three streaming passes beat that.
+// Column accumulation: float64 global atomics (global_atomic_add_f64; the memory side retires ~23.5 G scattered atomic
+// adds per second whatever their scope, tools/atomic_scope_probe.hip).  Large well-formed inputs send atomics for the
+// PREDICTED entries only (xc_confusion_csr_pred_side: fn starts from y_true's cached column sums).  A counting-sort form
+// (contributions bucketed by label and summed in LDS) was built in round 2, lost to both (2.7 vs 2.4 / 0.8 ms at 1 M x
+// 500 K, profiles/r02_confusion_timing.txt) and was removed in round 3.
 #include "xc_common.h"
 #include "xc_host.h"
 
@@ -150,177 +151,6 @@ __global__ __launch_bounds__(XC_BLOCK) void confusion_csr_kernel(
         confusion_row<T>(t_indptr, t_indices, t_data, p_indptr, p_indices, p_data, row, lane, sink, s_eidx[wib], s_eval[wib]);
 }
 
-// ---- bucketed form ---------------------------------------------------------------------
-// Pass 1 counts, per chunk of rows and per bucket of 2^shift consecutive labels, the contributions the chunk
-// emits; the two scans turn the counts into positions; pass 2 replays the rows and writes every contribution
-// {statistic | label, value} to its bucket's stream; pass 3 sums a bucket in an LDS table (3 x 2^shift float64)
-// and adds it to tp / fp / fn.  Summation order inside a bucket is the LDS atomics' (float64: differences of
-// the size of the global atomics' own, test_confusion_golden holds 1e-12 for both).
-#define XC_CF_CHUNKS_MAX 2048
-#define XC_CF_BUCKET_LABELS_MAX 2048 /* 3 x 2048 float64 = 48 KB of LDS */
-#define XC_CF_BUCKETS_MAX 16384      /* per-chunk counters: 64 KB of LDS */
-#define XC_CF_STAT_SHIFT 29
-
-struct ConfPlan {
-    int64_t n, m;
-    int shift, n_buckets, n_chunks;
-    int64_t rows_per_chunk;
-};
-
-template <typename T>
-struct __attribute__((aligned(8))) cf_item_t {
-    int32_t key; // statistic << XC_CF_STAT_SHIFT | label
-    T value;
-};
-
-struct CountSink {
-    int *hist;
-    int shift;
-    __device__ __forceinline__ void emit(int, int col, double) const { atomicAdd(&hist[col >> shift], 1); }
-};
-
-template <typename T>
-struct MoveSink {
-    int *cur; // next absolute position of this chunk in every bucket's stream
-    int shift;
-    cf_item_t<T> *items;
-    __device__ __forceinline__ void emit(int stat, int col, double v) const {
-        const int p = atomicAdd(&cur[col >> shift], 1);
-        cf_item_t<T> it;
-        it.key = (stat << XC_CF_STAT_SHIFT) | col;
-        it.value = (T)v; // every contribution is a T widened to float64: the round trip is exact
-        items[p] = it;
-    }
-};
-
-template <typename T, bool MOVE>
-__global__ __launch_bounds__(XC_BLOCK) void confusion_bucket_pass_kernel(
-    ConfPlan P, const int32_t *t_indptr, const int32_t *t_indices, const T *t_data, const int32_t *p_indptr,
-    const int32_t *p_indices, const T *p_data, int32_t *counts, const int64_t *base, cf_item_t<T> *items) {
-    extern __shared__ int s_tab[];
-    __shared__ int s_eidx[XC_BLOCK / XC_WAVE][XC_SEQ_CAP];
-    __shared__ double s_eval[XC_BLOCK / XC_WAVE][XC_SEQ_CAP];
-    for (int b = threadIdx.x; b < P.n_buckets; b += XC_BLOCK)
-        s_tab[b] = MOVE ? (int)base[b] + counts[(int64_t)b * P.n_chunks + blockIdx.x] : 0;
-    __syncthreads();
-    const int lane = lane_id();
-    const int wib = threadIdx.x >> 6;
-    const int64_t lo = (int64_t)blockIdx.x * P.rows_per_chunk;
-    const int64_t hi = lo + P.rows_per_chunk < P.n ? lo + P.rows_per_chunk : P.n;
-    if (MOVE) {
-        MoveSink<T> sink{s_tab, P.shift, items};
-        for (int64_t row = lo + wib; row < hi; row += XC_BLOCK / XC_WAVE)
-            confusion_row<T>(t_indptr, t_indices, t_data, p_indptr, p_indices, p_data, row, lane, sink, s_eidx[wib], s_eval[wib]);
-    } else {
-        CountSink sink{s_tab, P.shift};
-        for (int64_t row = lo + wib; row < hi; row += XC_BLOCK / XC_WAVE)
-            confusion_row<T>(t_indptr, t_indices, t_data, p_indptr, p_indices, p_data, row, lane, sink, s_eidx[wib], s_eval[wib]);
-        __syncthreads();
-        for (int b = threadIdx.x; b < P.n_buckets; b += XC_BLOCK) counts[(int64_t)b * P.n_chunks + blockIdx.x] = s_tab[b];
-    }
-}
-
-// one workgroup per bucket: exclusive scan of its counts over the chunks, and the bucket's total
-__global__ __launch_bounds__(XC_BLOCK) void confusion_scan_chunks_kernel(int n_chunks, int32_t *counts, int32_t *totals) {
-    __shared__ int s_part[XC_BLOCK];
-    int32_t *col = counts + (int64_t)blockIdx.x * n_chunks;
-    const int per = (n_chunks + XC_BLOCK - 1) / XC_BLOCK;
-    const int g0 = threadIdx.x * per, g1 = g0 + per < n_chunks ? g0 + per : n_chunks;
-    int sum = 0;
-    for (int g = g0; g < g1; ++g) sum += col[g];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < XC_BLOCK; ++i) {
-            const int v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
-        totals[blockIdx.x] = run;
-    }
-    __syncthreads();
-    int run = s_part[threadIdx.x];
-    for (int g = g0; g < g1; ++g) {
-        const int v = col[g];
-        col[g] = run;
-        run += v;
-    }
-}
-
-// exclusive scan of the bucket totals (one workgroup, the totals staged in LDS)
-__global__ __launch_bounds__(XC_BLOCK) void confusion_scan_buckets_kernel(int n_buckets, const int32_t *totals, int64_t *base) {
-    extern __shared__ int s_tot[];
-    __shared__ long long s_part[XC_BLOCK];
-    for (int b = threadIdx.x; b < n_buckets; b += XC_BLOCK) s_tot[b] = totals[b];
-    __syncthreads();
-    const int per = (n_buckets + XC_BLOCK - 1) / XC_BLOCK;
-    const int b0 = threadIdx.x * per, b1 = b0 + per < n_buckets ? b0 + per : n_buckets;
-    long long sum = 0;
-    for (int b = b0; b < b1; ++b) sum += s_tot[b];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long run = 0;
-        for (int i = 0; i < XC_BLOCK; ++i) {
-            const long long v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
-        base[n_buckets] = run;
-    }
-    __syncthreads();
-    long long run = s_part[threadIdx.x];
-    for (int b = b0; b < b1; ++b) {
-        base[b] = run;
-        run += s_tot[b];
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(XC_BLOCK) void confusion_bucket_reduce_kernel(ConfPlan P, const int64_t *base, const cf_item_t<T> *items,
-                                                                          double *tp, double *fp, double *fn) {
-    extern __shared__ double s_acc[];
-    const int labels = 1 << P.shift;
-    for (int i = threadIdx.x; i < 3 * labels; i += XC_BLOCK) s_acc[i] = 0.0;
-    __syncthreads();
-    const int64_t lo = base[blockIdx.x], hi = base[blockIdx.x + 1];
-    const int32_t first = (int32_t)blockIdx.x << P.shift;
-    for (int64_t t = lo + threadIdx.x; t < hi; t += XC_BLOCK) {
-        const cf_item_t<T> it = items[t];
-        const int stat = (int)((uint32_t)it.key >> XC_CF_STAT_SHIFT);
-        const int j = (it.key & ((1 << XC_CF_STAT_SHIFT) - 1)) - first;
-        atomicAdd(&s_acc[stat * labels + j], (double)it.value);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < labels; i += XC_BLOCK) {
-        const int64_t label = (int64_t)first + i;
-        if (label >= P.m) break;
-        const double a = s_acc[i], b = s_acc[labels + i], c = s_acc[2 * labels + i];
-        if (a != 0.0) tp[label] += a;
-        if (b != 0.0) fp[label] += b;
-        if (c != 0.0) fn[label] += c;
-    }
-}
-
-static ConfPlan make_conf_plan(int64_t n, int64_t m) {
-    ConfPlan P;
-    P.n = n;
-    P.m = m;
-    int shift = 6;
-    while (((m + (1ll << shift) - 1) >> shift) > 512 && (1 << shift) < XC_CF_BUCKET_LABELS_MAX) ++shift;
-    P.shift = shift;
-    P.n_buckets = (int)((m + (1ll << shift) - 1) >> shift);
-    int64_t chunks = (n + 127) / 128; // at least 128 rows (32 per wavefront) a chunk
-    if (chunks > XC_CF_CHUNKS_MAX) chunks = XC_CF_CHUNKS_MAX;
-    if (chunks < 1) chunks = 1;
-    P.rows_per_chunk = (n + chunks - 1) / chunks;
-    P.n_chunks = (int)((n + P.rows_per_chunk - 1) / P.rows_per_chunk);
-    return P;
-}
-
-static int64_t conf_items_bound(int64_t nnz_true, int64_t nnz_pred) { return 2 * nnz_pred + nnz_true; }
-
 // ---- prediction-side form ---------------------------------------------------------------
 // fn[j] = sum_i t_ij (1 - p_ij) runs over the stored entries of y_true -- 50 M atomics at 1 M x 500 K, of which
 // only the entries that MEET a predicted one (at most nnz(y_pred)) differ from the plain column sum of y_true:
@@ -429,29 +259,6 @@ __global__ __launch_bounds__(XC_BLOCK) void confusion_counts_kernel(int64_t n_k,
     if (lo < t_indptr[row + 1] && t_indices[lo] == label) atomic_add_f64(tp + label, 1.0);
 }
 
-template <typename T>
-static void launch_confusion_bucketed(const ConfPlan &P, const int32_t *t_indptr, const int32_t *t_indices, const void *t_data,
-                                      const int32_t *p_indptr, const int32_t *p_indices, const void *p_data, double *tp,
-                                      double *fp, double *fn, char *w, hipStream_t st) {
-    int32_t *counts = reinterpret_cast<int32_t *>(w);
-    w += ((int64_t)P.n_buckets * P.n_chunks * 4 + 63) / 64 * 64;
-    int32_t *totals = reinterpret_cast<int32_t *>(w);
-    w += ((int64_t)P.n_buckets * 4 + 63) / 64 * 64;
-    int64_t *base = reinterpret_cast<int64_t *>(w);
-    w += (((int64_t)P.n_buckets + 1) * 8 + 63) / 64 * 64;
-    cf_item_t<T> *items = reinterpret_cast<cf_item_t<T> *>(w);
-    const T *td = static_cast<const T *>(t_data), *pd = static_cast<const T *>(p_data);
-    const size_t tab_bytes = (size_t)P.n_buckets * 4;
-    hipLaunchKernelGGL((confusion_bucket_pass_kernel<T, false>), dim3(P.n_chunks), dim3(XC_BLOCK), tab_bytes, st, P, t_indptr,
-                       t_indices, td, p_indptr, p_indices, pd, counts, base, items);
-    hipLaunchKernelGGL(confusion_scan_chunks_kernel, dim3(P.n_buckets), dim3(XC_BLOCK), 0, st, P.n_chunks, counts, totals);
-    hipLaunchKernelGGL(confusion_scan_buckets_kernel, dim3(1), dim3(XC_BLOCK), tab_bytes, st, P.n_buckets, totals, base);
-    hipLaunchKernelGGL((confusion_bucket_pass_kernel<T, true>), dim3(P.n_chunks), dim3(XC_BLOCK), tab_bytes, st, P, t_indptr,
-                       t_indices, td, p_indptr, p_indices, pd, counts, base, items);
-    hipLaunchKernelGGL((confusion_bucket_reduce_kernel<T>), dim3(P.n_buckets), dim3(XC_BLOCK), (size_t)(3 << P.shift) * 8, st, P,
-                       base, items, tp, fp, fn);
-}
-
 } // namespace xc
 
 extern "C" {
@@ -475,40 +282,6 @@ int xc_confusion_csr(int64_t n, int64_t m, const int32_t *t_indptr, const int32_
                            static_cast<const double *>(t_data), p_indptr, p_indices, static_cast<const double *>(p_data),
                            tp, fp, fn, n_waves);
     XC_CHECK_LAUNCH("confusion_csr_kernel");
-    return XC_OK;
-}
-
-int xc_confusion_csr_workspace_bytes(int64_t n, int64_t m, int64_t nnz_true, int64_t nnz_pred, int dtype, int64_t *bytes) {
-    if (!bytes || n < 0 || m < 1 || nnz_true < 0 || nnz_pred < 0 || (dtype != XC_F32 && dtype != XC_F64))
-        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_workspace_bytes: bad argument");
-    const xc::ConfPlan P = xc::make_conf_plan(n, m);
-    *bytes = (int64_t)P.n_buckets * P.n_chunks * 4 + 64 + (int64_t)P.n_buckets * 4 + 64 + ((int64_t)P.n_buckets + 1) * 8 + 64 +
-             xc::conf_items_bound(nnz_true, nnz_pred) * (dtype == XC_F32 ? 8 : 16) + 64;
-    return XC_OK;
-}
-
-int xc_confusion_csr_bucketed(int64_t n, int64_t m, const int32_t *t_indptr, const int32_t *t_indices, const void *t_data,
-                              const int32_t *p_indptr, const int32_t *p_indices, const void *p_data, int dtype,
-                              int64_t nnz_true, int64_t nnz_pred, double *tp, double *fp, double *fn, void *workspace,
-                              void *stream) {
-    if (n < 0 || m < 1 || !t_indptr || !p_indptr || !tp || !fp || !fn || !workspace || nnz_true < 0 || nnz_pred < 0)
-        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_bucketed: NULL pointer or negative size");
-    if (dtype != XC_F32 && dtype != XC_F64) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_bucketed: unknown dtype %d", dtype);
-    if (m > (1ll << XC_CF_STAT_SHIFT) || xc::conf_items_bound(nnz_true, nnz_pred) > (int64_t)0x7fffffff)
-        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_bucketed: input too large for 32-bit positions (use xc_confusion_csr)");
-    if (n == 0) return XC_OK;
-    const xc::ConfPlan P = xc::make_conf_plan(n, m);
-    if (P.n_buckets > XC_CF_BUCKETS_MAX)
-        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_confusion_csr_bucketed: label space too large for the bucket tables (m <= %lld)",
-                            (long long)XC_CF_BUCKETS_MAX * XC_CF_BUCKET_LABELS_MAX);
-    hipStream_t st = xc::as_stream(stream);
-    if (dtype == XC_F32)
-        xc::launch_confusion_bucketed<float>(P, t_indptr, t_indices, t_data, p_indptr, p_indices, p_data, tp, fp, fn,
-                                         static_cast<char *>(workspace), st);
-    else
-        xc::launch_confusion_bucketed<double>(P, t_indptr, t_indices, t_data, p_indptr, p_indices, p_data, tp, fp, fn,
-                                          static_cast<char *>(workspace), st);
-    XC_CHECK_LAUNCH("confusion bucket kernels");
     return XC_OK;
 }
 

@@ -116,8 +116,12 @@ def exchange_changes(comm: "TorchComm", records: torch.Tensor, snapshot: torch.T
 #     4e-4 / S (uniform) .. 6e-3 / S (Zipf, where every row changes) and heals in the following sweeps.
 # "auto": as many exchanges as the sweep is expected to change rows (up to EXCHANGES_MAX), never fewer than
 # the number that keeps the iteration contracting for the shard count.
-EXCHANGES_MAX = 8
-_EXCHANGE_PER_CHANGED_SHARE = 16.0   # S = ceil(this * share of rows the sweep is expected to change)
+import os as _os
+
+# Round 3: 16 / 32 (round 2: 8 / 16) -- 8 shards, 24 K x 1.5 K: 2.0e-5, 6.1e-6, 2.2e-6, ... per sweep (was 4.5e-5, 1.5e-5,
+# 4.3e-6); 32 / 64 holds 1e-5 from the first sweep on (7.6e-6, 3.5e-6, 1.5e-6) at twice the exchanges.
+EXCHANGES_MAX = int(_os.environ.get("XCOLUMNS_BCA_EXCHANGES_MAX", "16"))
+_EXCHANGE_PER_CHANGED_SHARE = float(_os.environ.get("XCOLUMNS_BCA_EXCHANGE_FACTOR", "32"))   # S = ceil(this * share of rows the sweep is expected to change)
 
 
 def min_exchanges(world: int) -> int:

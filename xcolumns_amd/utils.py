@@ -314,6 +314,12 @@ class DeviceNumpyOrders:
         self.ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=device)
         self.bufs = [torch.empty(max(1, self.n), dtype=torch.int32, device=device) for _ in range(self.DEPTH)]
         self.side = torch.cuda.Stream(device=device) if self.ahead > 0 else None
+        if self.side is not None:
+            # the side stream works on these tensors: the allocator must not hand their memory to anybody else before
+            # that work has finished, even if this object is dropped without finish()
+            self.ws.record_stream(self.side)
+            for b in self.bufs:
+                b.record_stream(self.side)
         mask = (1 << 64) - 1
         words = (ctypes.c_uint64 * 4)(base >> 64, base & mask, self._inc >> 64, self._inc & mask)
         with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
@@ -325,6 +331,13 @@ class DeviceNumpyOrders:
         self._free = {}             # order number -> event on the consumer's stream recorded when the NEXT order was handed out
         for _ in range(self.ahead):
             self._generate()
+
+    def __del__(self):
+        try:
+            if self.side is not None:
+                self.side.synchronize()
+        except Exception:
+            pass
 
     def _generate(self):
         """Enqueue shuffle number generated + 1: bufs[k % DEPTH] <- shuffle of bufs[(k - 1) % DEPTH]."""
