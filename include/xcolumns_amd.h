@@ -445,7 +445,8 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
  * ctrl: float64[XC_CTRL_SIZE] on the device.  Ring slot s (s < XC_CTRL_RING_SLOTS) is
  * XC_CTRL_RING_STRIDE doubles at ctrl[XC_CTRL_RING + XC_CTRL_RING_STRIDE s]: {utility sum,
  * rows changed, wavefronts of the sweep, 0 = continue | 1 = rule fired | 2 = step
- * skipped, sequence number (host ring only)}.  The host ring (pinned, host-mapped:
+ * skipped | 3 = paused: the rule left the NEXT sweep fewer than exact_below wavefronts, it is the
+ * host's to run exactly (the steps enqueued behind report 2), sequence number (host ring only)}.  The host ring (pinned, host-mapped:
  * xc_host_alloc_pinned of XC_CTRL_RING_STRIDE * XC_CTRL_RING_SLOTS doubles) has the
  * same slots; the boundary kernel stores into it directly, sequence number last.
  * ------------------------------------------------------------------------- */
@@ -460,6 +461,7 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
 #define XC_CTRL_MIN_WAVES 8
 #define XC_CTRL_MAX_WAVES 9
 #define XC_CTRL_FIXED_WAVES 10
+#define XC_CTRL_EXACT_BELOW 11 /* a sweep the rule leaves fewer wavefronts than this is the host's to run exactly: the loop pauses */
 #define XC_CTRL_RING 16
 #define XC_CTRL_RING_SLOTS 8
 #define XC_CTRL_RING_STRIDE 8 /* doubles per slot: 4 results, the sequence number, padding */
@@ -471,10 +473,10 @@ int xc_utility_vectors(int64_t m, int64_t n_norm, const double *stats,
  * the next sweep = fixed_waves if > 0, else
  * clamp(floor(policy_num / max(1, changed / world)), min_waves, max_waves) (changed = rows
  * changed over all ranks);
- * `first_waves` is used by the first sweep. */
+ * `first_waves` is used by the first sweep; `exact_below` (0: never): see flag 3 above. */
 int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance, double divisor,
                           int maximize, double policy_num, int world, int min_waves,
-                          int max_waves, int fixed_waves, int first_waves, void *stream);
+                          int max_waves, int fixed_waves, int first_waves, int exact_below, void *stream);
 
 /* Positions [first, first + count) of a full, non-greedy sweep over `order`
  * (xc_bca_plan_sweep with acc), launched for max_waves wavefronts; runs only if the

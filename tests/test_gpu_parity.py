@@ -1113,3 +1113,61 @@ def test_bca_csr_label_space_beyond_the_packed_stream(oref):
             assert diff.max() < 1e-12 and np.array_equal(Pg.indices, Po.indices)
         else:
             assert diff[-1] < FINAL_TOL and diff.max() < PER_SWEEP_TOL
+
+
+def test_device_side_loop_pauses_for_exact_sweeps(oref, monkeypatch):
+    """The device-side loop hands a sweep back to the host when its wavefront rule falls below the policy's
+    exact-sweep threshold (XC_CTRL_EXACT_BELOW, flag 3): the sweep that was already enqueued does nothing, the host runs
+    it with the SAME visiting order, and the loop is armed again afterwards.  Forced here after every sweep: every
+    order is consumed exactly once, in sequence, and the trace stays the sequential oracle's (the host's sweeps are the
+    exact ones, the device's run 64 wavefronts on 30 K rows)."""
+    import xcolumns_amd.block_coordinate as bc
+    n, m, k, sweeps = 30000, 3000, 5, 6
+    Y = _synthetic_csr(n, m, 30, 77)
+    calls = {"host": 0, "device": 0}
+
+    class AlternatingPolicy(bc.WavePolicy):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self.sequential_below = 10 ** 9          # the device rule always pauses after the sweep it ran
+            self._turn = 0
+
+        def next(self, changed_prev=None, greedy=False):
+            # the host's question "how wide is the next sweep": concurrent (64) and exact (1) alternately
+            return 64
+
+    seen = []
+    orig_step, orig_sweep = bc.BcaCsrEngine.pipeline_step, bc.BcaCsrEngine.sweep
+
+    def spy_step(self, order, j, n_u):
+        seen.append(("device", j, order.cpu().numpy().copy()))
+        return orig_step(self, order, j, n_u)
+
+    def spy_sweep(self, order, n_order, n_waves, greedy=False):
+        seen.append(("host", None, order.cpu().numpy().copy()))
+        return orig_sweep(self, order, n_order, n_waves, greedy=greedy)
+
+    monkeypatch.setattr(bc, "WavePolicy", AlternatingPolicy)
+    monkeypatch.setattr(bc.BcaCsrEngine, "pipeline_step", spy_step)
+    monkeypatch.setattr(bc.BcaCsrEngine, "sweep", spy_sweep)
+    Pg, mg = bc.predict_optimizing_macro_f1_score_using_bc(Y, k, seed=13, max_iters=sweeps, tolerance=-1.0, return_meta=True)
+    metric = oref.make_metric(oref.FBETA, k=float(k), m=float(m))
+    _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=sweeps, tolerance=-1.0)
+    assert mg["iters"] == sweeps and len(mg["utilities"]) == sweeps
+    d = np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"]))
+    print("paused after every sweep, |utility - oracle| per sweep:", d)
+    assert d.max() < PER_SWEEP_TOL
+    # the sweeps that ran: device sweeps j = 1 .. K, each followed by a no-op'd enqueue of j + 1 that is re-issued
+    ran = [s for s in seen if s[0] == "device"]
+    rng, order = np.random.default_rng(13), np.arange(n)
+    expected = []
+    for _ in range(sweeps):
+        rng.shuffle(order)
+        expected.append(order.astype(np.int32).copy())
+    by_j = {}
+    for _, j, o in ran:
+        by_j.setdefault(j, []).append(o)
+    assert sorted(by_j) == list(range(1, sweeps + 1)) or sorted(by_j) == list(range(1, sweeps + 2))
+    for j in range(1, sweeps + 1):
+        for o in by_j[j]:                    # enqueued (and paused), then re-issued: the same order both times
+            assert np.array_equal(o, expected[j - 1]), j

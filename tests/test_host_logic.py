@@ -269,25 +269,27 @@ def test_wave_policy_rules():
     orig = bc._lib.device_info
     bc._lib.device_info = lambda: monkey_info
     try:
+        B = bc._BETA                       # round 3: 0.025 (half of round 2's); the first sweep from top-k runs at half the width
+        assert B == 0.025
         p = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5)
-        assert p.next(None) == int(0.05 * 30_000) == 1500
-        assert p.next(50_000) == 1500 and p.next(25_000) == 3000 and p.next(10) == 8192      # cap = resident waves
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(None) == 750             # longer rows: more candidates per row
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(None) == 375             # (5 / k)^2
+        assert p.next(None) == int(B * 30_000 * 0.5) == 375
+        assert p.next(50_000) == 750 and p.next(25_000) == 1500 and p.next(10) == 8192          # cap = resident waves
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=100, k=5).next(50_000) == 375           # longer rows: more candidates per row
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=10).next(50_000) == 187           # (5 / k)^2
         z = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True)
-        assert z.first_sequential and z.next(None) == 1 and z.next(100_000) == 750            # < 64 wavefronts: sequential
+        assert z.first_sequential and z.next(None) == 1 and z.next(100_000) == 375            # < 64 wavefronts: the exact sweep
         zf = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True, parity="final")
-        assert not zf.first_sequential and zf.next(None) == 6000       # what a wide first sweep leaves heals in the second
+        assert not zf.first_sequential and zf.next(None) == 3000       # what a wide first sweep leaves heals in the second
         zf1 = bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, skewed=True, parity="final", sweeps=1)
-        assert zf1.next(None) == int(6000 * 0.0616 * 30_000 / 200_000) == 55                # ... unless there is no second
+        assert zf1.next(None) == int(3000 * 0.1232 * 30_000 / 200_000) == 55                # ... unless there is no second
         zl = bc.WavePolicy(1_000_000, m=500_000, row_nnz=50, k=5, skewed=True)
-        assert not zl.first_sequential and zl.next(None) == int(0.05 * 500_000 * (10 / 12) ** 2.5 * 0.0616) == 976                                   # only the FIRST sweep is narrowed
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 6000
+        assert not zl.first_sequential and zl.next(None) == int(B * 500_000 * (10 / 12) ** 2.5 * 0.1232) == 976   # only the FIRST sweep is narrowed
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None) == 1500
         num, world, min_w, max_w, fixed = p.device_params()
         assert int(num / 50_000) == p.next(50_000) and (world, fixed, max_w) == (1, 0, 8192)
         assert bc.WavePolicy(100_000, fixed=1, m=30_000).sequential
         s = bc.WavePolicy(12_500, m=30_000, row_nnz=50, k=5, world=8)                           # 8 row shards
-        assert s.next(400_000) == int(0.05 * 30_000 * 12_500 / 2 / 50_000)                      # its share of the changed rows
+        assert s.next(400_000) == int(B * 30_000 * 12_500 / 2 / 50_000)                         # its share of the changed rows
         g = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5)                                   # ~1 predicted row per label
         assert g.sequential and g.next(None) == 1 and g.next(10) == 1
         # rules the round-2 fuzz added (profiles/r02_fuzz_concurrent.txt): all sequential under the per-sweep bar
@@ -298,7 +300,9 @@ def test_wave_policy_rules():
         assert p.next(None, greedy=True) == 1                                                       # greedy first sweep
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=50, k=5, parity="final").next(None, greedy=True) > 1
         zs = bc.WavePolicy(40_000, m=40_000, row_nnz=50, k=5, skewed=True)
-        assert zs.sequential_below == 64 and zs.next(40_000) > 64 and zs.next(100) > 64 and bc.WavePolicy(40_000, m=40_000, row_nnz=50, k=5, skewed=True, scale=0.25).next(40_000) == 1             # a later sweep below 64 wavefronts
+        # a later sweep on skewed labels that the rule leaves fewer than 64 wavefronts runs exactly (the device-side loop
+        # pauses for it: XC_CTRL_EXACT_BELOW)
+        assert zs.sequential_below == 64 and zs.next(10_000) > 64 and zs.next(100) > 64 and zs.next(40_000) == 1
         assert bc.WavePolicy(100_000, m=30_000, row_nnz=10, k=5).next(None) == p.next(None)          # short rows do not widen
         gf = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5, parity="final")
         # "final" parity takes the whole GPU there: the width does not move the difference on such a shape (r02_c3_width.txt)

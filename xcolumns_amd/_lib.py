@@ -68,7 +68,7 @@ SIGNATURES = {
     "xc_bca_colsum_csr": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "xc_bca_expand_colsum": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_bca_pipeline_begin": (c_int, [c_void_p, c_double, c_double, c_double, c_int, c_double, c_int, c_int, c_int,
-                                      c_int, c_int, c_void_p]),
+                                      c_int, c_int, c_int, c_void_p]),
     "xc_bca_plan_sweep_pipelined": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "xc_bca_plan_boundary_pipelined": (c_int, [c_void_p, c_int64, c_double, c_int, c_void_p, c_int, c_void_p,
                                                c_double, c_void_p]),

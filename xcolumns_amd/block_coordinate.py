@@ -727,7 +727,7 @@ class BcaCsrEngine:
         self._pipe_max_waves = max(2, max_w)
         _lib.call("xc_bca_pipeline_begin", D.ptr(self._ctrl), float(old_utility_sum), float(tolerance), float(divisor),
                   int(bool(maximize)), float(num), int(world), int(min_w), int(max_w), int(fixed),
-                  int(max(1, min(first_waves, max_w))), D.stream())
+                  int(max(1, min(first_waves, max_w))), int(getattr(policy, "sequential_below", 0)), D.stream())
 
     def _delta_sharded(self) -> bool:
         """Row shards whose pipelined sweeps leave their changes in the float64 records (xc_bca_set_acc_delta)
@@ -821,8 +821,9 @@ class BcaCsrEngine:
         self._partial_sweep = False
 
     def pipeline_result(self, j: int):
-        """(utility sum, rows changed, wavefronts used, flag) of boundary j; flag 0 = continue,
-        1 = the stopping rule fired there, 2 = the step did not run.  Blocks until it is known."""
+        """(utility sum, rows changed, wavefronts used, flag) of boundary j; flag 0 = continue, 1 = the stopping rule
+        fired there, 2 = the step did not run, 3 = the loop paused there: the policy wants the NEXT sweep exact
+        (WavePolicy.sequential_below), it is the host's to run.  Blocks until it is known."""
         slot = j % _lib.XC_CTRL_RING_SLOTS
         _lib.call("xc_bca_ring_wait", self._ring_ptr, slot, self._seq_of[slot], 600000.0, D.stream())
         r, o = self._ring, _lib.XC_CTRL_RING_STRIDE * slot
@@ -1175,25 +1176,35 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
     sweep -> recompute, utility -> stopping rule.  `eng` is a :class:`BcaCsrEngine`
     (or anything with its methods: the multi-rank CPU tests inject a checker-backed
     one); with sharded rows every rank runs this loop and reaches the same decision
-    because utilities come from all-reduced statistics."""
+    because utilities come from all-reduced statistics.
+
+    Sweeps the policy runs concurrently are handed to the GPU in one go (:func:`_run_pipelined`: stopping rule and
+    wavefront policy on the device); sweeps it wants exact (the ordered parallel sweep / one wavefront) are paced
+    here.  The device-side loop hands back ("pauses") when its rule asks for an exact sweep."""
     changed_prev = None
     new_utility = None
     new_utility_sum = None
+    pending_order = None      # the order of a sweep the device-side loop enqueued but did not run (it paused before it)
     div = m if metric_aggregation == "mean" else 1
-    for j in range(1, max_iters + 1):
+    j = 1
+    while j <= max_iters:
         if (not greedy and not getattr(policy, "sequential", True) and hasattr(eng, "can_pipeline")
                 and eng.can_pipeline(n_order) and policy.next(changed_prev) > 1):
-            # every remaining sweep is a full concurrent one: hand the stopping rule to the GPU
+            # the remaining sweeps are concurrent ones (until the rule says otherwise): hand the stopping rule to the GPU
             if new_utility_sum is None:
                 if j == 1:
                     eng.reset_state(False)
                 log_info("    Calculating expected confusion matrix ...", verbose)
                 new_utility_sum = eng.recompute_utility_sum(n_u)
-            _run_pipelined(eng, next_order, n_u, div, maximize, tolerance, max_iters, j, new_utility_sum,
-                           changed_prev, policy, verbose, meta)
-            return
+            paused = _run_pipelined(eng, next_order, n_u, div, maximize, tolerance, max_iters, j, new_utility_sum,
+                                    changed_prev, policy, verbose, meta, pending_order)
+            if paused is None:
+                return
+            j, pending_order, new_utility_sum, changed_prev = paused
+            new_utility = new_utility_sum / div
+            continue
         log_info(f"  Starting iteration {j}/{max_iters} ...", verbose)
-        order = next_order()
+        order, pending_order = (pending_order, None) if pending_order is not None else (next_order(), None)
         if j == 1:
             eng.reset_state(greedy)
         if greedy:
@@ -1235,19 +1246,26 @@ def run_bca_sweeps(eng, next_order: Callable, n_order: int, n_u: int, m: int, me
         if (maximize and new_utility - old_utility < tolerance) or (not maximize and new_utility - old_utility > tolerance):
             log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
             break
+        j += 1
 
 
 def _run_pipelined(eng, next_order: Callable, n_u: int, div: float, maximize: bool, tolerance: float, max_iters: int,
-                   j0: int, old_sum: float, changed_prev, policy, verbose: bool, meta: Dict[str, Any]) -> None:
+                   j0: int, old_sum: float, changed_prev, policy, verbose: bool, meta: Dict[str, Any], first_order=None):
     """Sweeps j0.. of the loop above with the stopping rule (block_coordinate.py:486-493) and the
     wavefront policy evaluated on the GPU: sweep j + 1 is enqueued before the utility of sweep j has
     reached the host; if the rule fired at boundary j it is a no-op.  Same utilities, same decision,
-    same prediction as the host-paced loop -- the GPU just never waits for Python."""
+    same prediction as the host-paced loop -- the GPU just never waits for Python.
+
+    Returns None when the run is over, or (j, order, utility sum, rows changed) when the device-side policy PAUSED after
+    sweep j - 1: it wants sweep j exact; `order` is the visiting order that sweep was enqueued with (it did not run)."""
     eng.pipeline_begin(old_sum, tolerance, div, maximize, policy, policy.next(changed_prev))
     prev = [old_sum / div]
+    last = {}
 
-    def collect(j) -> bool:
+    def collect(j) -> int:
         total, changed, waves, flag = eng.pipeline_result(j)
+        if flag == 2:
+            return 2
         new_utility = total / div
         meta["iters"] = j
         meta["utilities"].append(new_utility)
@@ -1256,15 +1274,25 @@ def _run_pipelined(eng, next_order: Callable, n_u: int, div: float, maximize: bo
         log_info(f"    Iteration {j}/{max_iters} finished ({waves} wavefronts, {changed} rows changed), expected "
                  f"metric value: {prev[0]} -> {new_utility}", verbose)
         prev[0] = new_utility
+        last.update(total=total, changed=changed)
         if flag == 1:
             log_info(f"  Stopping because improvement of expected metric value is smaller than {tolerance}", verbose)
-        return flag == 1
+        return flag
 
+    orders = {}
     for j in range(j0, max_iters + 1):
-        eng.pipeline_step(next_order(), j, n_u)
-        if j > j0 and collect(j - 1):
-            return
-    collect(max_iters)
+        orders[j] = first_order if (j == j0 and first_order is not None) else next_order()
+        eng.pipeline_step(orders[j], j, n_u)
+        if j > j0:
+            flag = collect(j - 1)
+            orders.pop(j - 1, None)
+            if flag == 1:
+                return None
+            if flag == 3:      # paused after sweep j - 1: sweep j was enqueued with orders[j] and did nothing
+                eng.pipeline_result(j)           # (its boundary reports "did not run": drain it before the host takes over)
+                return j, orders[j], last["total"], last["changed"]
+    flag = collect(max_iters)
+    return None
 
 
 def _initial_csr_indices(y_proba, init_y_pred, k: int, seed):

@@ -939,7 +939,7 @@ __global__ __launch_bounds__(XC_BLOCK) void commit_utility_kernel(int64_t m, dou
 // seen the utility of sweep j: a sweep launched after the rule fired is a no-op.
 __global__ void bca_ctrl_init_kernel(double *ctrl, double old_sum, double tolerance, double divisor, int maximize,
                                      double policy_num, double world, double min_waves, double max_waves,
-                                     double fixed_waves, double first_waves) {
+                                     double fixed_waves, double first_waves, double exact_below) {
     if (threadIdx.x != 0) return;
     ctrl[XC_CTRL_STOP] = 0.0;
     ctrl[XC_CTRL_OLD_SUM] = old_sum;
@@ -952,6 +952,7 @@ __global__ void bca_ctrl_init_kernel(double *ctrl, double old_sum, double tolera
     ctrl[XC_CTRL_MIN_WAVES] = min_waves;
     ctrl[XC_CTRL_MAX_WAVES] = max_waves;
     ctrl[XC_CTRL_FIXED_WAVES] = fixed_waves;
+    ctrl[XC_CTRL_EXACT_BELOW] = exact_below;
 }
 
 // The order every sum of the XC_UTILITY_PARTIALS partials uses, on the GPU and on the host
@@ -989,20 +990,6 @@ __global__ __launch_bounds__(XC_UTILITY_PARTIALS / 2) void bca_boundary_finish_k
     const double tol = ctrl[XC_CTRL_TOLERANCE];
     const bool stop = ctrl[XC_CTRL_MAXIMIZE] != 0.0 ? (new_u - old_u < tol) : (new_u - old_u > tol); // :486-489
     const double used = ctrl[XC_CTRL_WAVES]; // wavefronts the sweep before this boundary used
-    ring[0] = total;
-    ring[1] = changed;
-    ring[2] = used;
-    ring[3] = stop ? 1.0 : 0.0;
-    if (hring) { // straight into the host's pinned ring: no copy engine, no event in the stream
-        hring[0] = total;
-        hring[1] = changed;
-        hring[2] = used;
-        hring[3] = stop ? 1.0 : 0.0;
-        __threadfence_system();
-        hring[4] = seq;
-    }
-    ctrl[XC_CTRL_OLD_SUM] = total;
-    ctrl[XC_CTRL_STOP] = stop ? 1.0 : 0.0;
     // wavefronts of the next sweep: block_coordinate.WavePolicy.next
     const double max_w = ctrl[XC_CTRL_MAX_WAVES];
     double w;
@@ -1014,6 +1001,25 @@ __global__ __launch_bounds__(XC_UTILITY_PARTIALS / 2) void bca_boundary_finish_k
         w = floor(ctrl[XC_CTRL_POLICY_NUM] / c);
         if (w < ctrl[XC_CTRL_MIN_WAVES]) w = ctrl[XC_CTRL_MIN_WAVES];
     }
+    // A sweep the rule leaves fewer wavefronts than EXACT_BELOW belongs to the exact (ordered) sweep, which the host
+    // paces: the loop PAUSES -- the sweep already enqueued behind this boundary finds the stop flag and does nothing,
+    // the host reads flag 3, runs that sweep itself and may arm the loop again (block_coordinate.run_bca_sweeps).
+    const bool pause = !stop && ctrl[XC_CTRL_FIXED_WAVES] <= 0.0 && w < ctrl[XC_CTRL_EXACT_BELOW];
+    const double flag = stop ? 1.0 : (pause ? 3.0 : 0.0);
+    ring[0] = total;
+    ring[1] = changed;
+    ring[2] = used;
+    ring[3] = flag;
+    if (hring) { // straight into the host's pinned ring: no copy engine, no event in the stream
+        hring[0] = total;
+        hring[1] = changed;
+        hring[2] = used;
+        hring[3] = flag;
+        __threadfence_system();
+        hring[4] = seq;
+    }
+    ctrl[XC_CTRL_OLD_SUM] = total;
+    ctrl[XC_CTRL_STOP] = (stop || pause) ? 1.0 : 0.0;
     if (w > max_w) w = max_w;
     if (w < 1.0) w = 1.0;
     ctrl[XC_CTRL_WAVES] = w;
@@ -1530,12 +1536,12 @@ int xc_bca_plan_boundary(void *plan, int64_t n_norm_utility, double n_counted, i
 // ---- the sweep loop without a host round trip per iteration ---------------------------
 int xc_bca_pipeline_begin(double *ctrl, double old_utility_sum, double tolerance, double divisor, int maximize,
                           double policy_num, int world, int min_waves, int max_waves, int fixed_waves, int first_waves,
-                          void *stream) {
+                          int exact_below, void *stream) {
     if (!ctrl || max_waves < 1 || first_waves < 1 || divisor <= 0.0)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_pipeline_begin: bad argument");
     hipLaunchKernelGGL(xc::bca_ctrl_init_kernel, dim3(1), dim3(XC_WAVE), 0, xc::as_stream(stream), ctrl, old_utility_sum,
                        tolerance, divisor, maximize, policy_num, (double)(world < 1 ? 1 : world), (double)min_waves,
-                       (double)max_waves, (double)fixed_waves, (double)first_waves);
+                       (double)max_waves, (double)fixed_waves, (double)first_waves, (double)(exact_below < 0 ? 0 : exact_below));
     XC_CHECK_LAUNCH("bca_ctrl_init_kernel");
     return XC_OK;
 }
