@@ -399,8 +399,14 @@ def worker(args):
         if comm is not None:
             per_sweep = max(1, (args.warmup + args.steps * repeats))
             extra = (sum(used) / len(used) - 1.0) if eng.shadow is not None else 0.0
+            n_exch = sum(used) / len(used) - 1.0 if eng.shadow is not None else 0.0
+            ar = _median([x / args.steps for x in res["allreduce_ms"]]) if res["allreduce_ms"] else None
             res["comm"] = {"backend": backend, "world_size": dist.get_world_size(),
+                           "world_size_seen": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
                            "exchanges_per_sweep": used,
+                           "boundary_all_reduce_bytes": (2 * m + 1) * 8, "mid_sweep_exchange_bytes": 2 * m * 4,
+                           "collectives_per_sweep": 1.0 + n_exch,
+                           "ms_per_collective": (ar / (1.0 + n_exch)) if ar is not None else None,
                            "all_reduce_bytes_per_sweep": (2 * m + 1) * 8 + extra * 2 * m * 4,
                            "all_reduce_bytes_note": "boundary: 2m+1 float64 (from-scratch tp/fp + changed-row count); each "
                                                     "mid-sweep exchange: 2m float32 (what the rank's rows changed in the records)",
@@ -417,6 +423,14 @@ def worker(args):
         del main["eng"]
         torch.cuda.empty_cache()
         strong = one_mode("strong", args.zipf, max(1, min(args.repeats, 3)))
+        strong["eng"].close()
+        del strong["eng"]
+        torch.cuda.empty_cache()
+        if not args.no_sharded_parity:
+            try:
+                strong["comm"]["sharded_vs_oracle"] = sharded_parity_leg(args, comm, rank, world, matrices[("strong", bool(args.zipf))][0])
+            except Exception as e:  # identical on every rank up to the oracle call, which only rank 0 makes
+                strong["comm"]["sharded_vs_oracle"] = {"error": repr(e)}
 
     out = None
     if rank == 0:
@@ -583,6 +597,33 @@ def worker(args):
         dist.destroy_process_group()
 
 
+def sharded_parity_leg(args, comm, rank, world, Y_shard, sweeps=2):
+    """The public sharded call (xcolumns_amd.distributed.predict_bca_csr_sharded, default exchange schedule and width
+    policy) on the SAME workload matrix split over the ranks, `sweeps` sweeps from top-k; rank 0 then runs the
+    sequential oracle on the whole matrix with the same seed: |utility difference| after every sweep (bar 1e-5)."""
+    from xcolumns_amd.distributed import predict_bca_csr_sharded
+    from xcolumns_amd.metrics import binary_f1_score_on_conf_matrix
+    from xcolumns_amd.synthetic import WORKLOADS, make_csr_rows
+
+    n, m = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    _, meta = predict_bca_csr_sharded(Y_shard, binary_f1_score_on_conf_matrix, K, comm, skip_tn=True, seed=ORDER_SEED,
+                                      max_iters=sweeps, tolerance=-1.0)
+    t_call = time.perf_counter() - t0
+    out = {"workload": f"{args.workload} split over {world} ranks, {sweeps} sweeps, seed {ORDER_SEED}, default policy and exchange schedule",
+           "bar": 1e-5, "utility_by_sweep": [float(u) for u in meta["utilities"]], "exchanges_per_sweep": meta.get("exchanges"),
+           "call_s": t_call}
+    if rank == 0:
+        from oracle import ref as oracle_ref   # checker only, outside every timed region
+        Y = make_csr_rows(n, m, 0, n, R_NNZ, seed=MATRIX_SEED, zipf=args.zipf, k=K)
+        metric = oracle_ref.make_metric(oracle_ref.FBETA, k=float(K), m=float(m))
+        t0 = time.perf_counter()
+        _, mo = oracle_ref.predict_using_bc_with_0approx(Y, metric, K, skip_tn=True, seed=ORDER_SEED, max_iters=sweeps, tolerance=-1.0)
+        d = np.abs(np.asarray(meta["utilities"]) - np.asarray(mo["utilities"]))
+        out.update(abs_diff_by_sweep=[float(x) for x in d], max=float(d.max()), oracle_s=time.perf_counter() - t0)
+    return out
+
+
 def api_call_leg(Y, sweeps):
     """rows/s of ONE predict_optimizing_macro_f1_score_using_bc(y_proba, k, tolerance < 0, max_iters = K) call:
     BASELINE.md section 4's definition of the metric (wall time of the call).  From a scipy matrix in host memory
@@ -726,6 +767,8 @@ def main():
                          "final (wider sweeps, the bar holds after the last sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-zipf", action="store_true", help="skip the Zipf leg of the default run")
+    ap.add_argument("--no-sharded-parity", action="store_true",
+                    help="N > 1: skip the sharded-vs-oracle leg (two sweeps of the sequential oracle on rank 0, about 40 s)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the main timed loop (profiling runs): no f64-record / API / Zipf / parity legs, no strong_scaling object")
     args = ap.parse_args()

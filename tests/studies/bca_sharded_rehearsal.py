@@ -14,8 +14,13 @@ from xcolumns_amd.metrics import binary_f1_score_on_conf_matrix
 from xcolumns_amd.synthetic import make_csr
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend = os.environ.get("XC_REHEARSAL_BACKEND", "gloo")   # "nccl" (= RCCL): one GPU per rank, the multi-GPU node's form
+if backend == "nccl":
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+else:
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 shape = os.environ.get("XC_BCA_REHEARSAL_SHAPE")   # "n,m,sweeps": the benchmark generator at that size, no sequential oracle
 if shape:
     from xcolumns_amd.synthetic import make_csr_rows
@@ -32,7 +37,7 @@ comm = TorchComm()
 P, meta = predict_bca_csr_sharded(shard, binary_f1_score_on_conf_matrix, k, comm, skip_tn=True,
                                   seed=13, max_iters=sweeps, tolerance=tol)
 gathered = [None] * world
-dist.all_gather_object(gathered, (meta["utilities"], meta["iters"], P.indices))
+dist.all_gather_object(gathered, (meta["utilities"], meta["iters"], P.indices, torch.cuda.current_device()))
 if rank == 0:
     sys.path.insert(0, "tests")
     from oracle import ref as oref   # checker (this script is a rehearsal, not product code)
@@ -44,12 +49,15 @@ if rank == 0:
         Y = make_csr_rows(n, m, 0, n, 50, seed=20240004, k=k)
     tp, fp, fn, tn = oref.calculate_confusion_matrix(Y, full, skip_tn=True)
     u = oref.calculate_utility(metric, "mean", tp / n, fp / n, fn / n, tn / n)
-    if shape:
+    if shape and os.environ.get("XC_BCA_REHEARSAL_ORACLE") != "1":
         mo = {"utilities": []}
+    elif shape:
+        _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=sweeps, tolerance=-1.0)
     else:
         _, mo = oref.predict_using_bc_with_0approx(Y, metric, k, skip_tn=True, seed=13, max_iters=6, tolerance=1e-7)
     print("utilities", meta["utilities"], "\noracle   ", mo["utilities"], "\nexchanges", meta.get("exchanges"),
-          "\n|last - utility(assembled prediction)| =", abs(u - meta["utilities"][-1]), "all-reduce calls", comm.calls, flush=True)
+          "\n|last - utility(assembled prediction)| =", abs(u - meta["utilities"][-1]), "all-reduce calls", comm.calls,
+          "\nbackend", dist.get_backend(), "devices", sorted({int(g[3]) for g in gathered}), flush=True)
     assert abs(u - meta["utilities"][-1]) < 1e-12
 dist.barrier()
 dist.destroy_process_group()

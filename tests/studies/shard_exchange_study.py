@@ -14,6 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
+def _matrix(n, m, zipf):
+    """XC_STUDY_ROWS_GEN=1: the benchmark generator the GPU rehearsal (bca_sharded_rehearsal.py) uses at a custom shape."""
+    from xcolumns_amd.synthetic import make_csr, make_csr_rows
+    if os.environ.get("XC_STUDY_ROWS_GEN") == "1":
+        return make_csr_rows(n, m, 0, n, 50, seed=20240004, zipf=zipf, k=5)
+    return make_csr(n, m, 50, seed=20240001, zipf=zipf)
+
+
 def worker(rank, world, port, n, m, settings, zipf, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -24,7 +32,7 @@ def worker(rank, world, port, n, m, settings, zipf, q):
     from xcolumns_amd.metrics import binary_f1_score_on_conf_matrix
     from xcolumns_amd.synthetic import make_csr
 
-    Y = make_csr(n, m, 50, seed=20240001, zipf=zipf)
+    Y = _matrix(n, m, zipf)
     comm = TorchComm()
     shard = shard_csr(Y, world, rank)
     for S in settings:
@@ -44,14 +52,16 @@ if __name__ == "__main__":
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 12_000
-    for zipf in (False, True):
-        Y = make_csr(n, m, 50, seed=20240001, zipf=zipf)
+    worlds = [int(x) for x in os.environ.get("XC_STUDY_WORLDS", "2,8").split(",")]
+    sets = [x if x == "auto" else int(x) for x in os.environ.get("XC_STUDY_SETTINGS", "1,2,4,8,auto").split(",")]
+    for zipf in ((False,) if os.environ.get("XC_STUDY_UNIFORM_ONLY") == "1" else (False, True)):
+        Y = _matrix(n, m, zipf)
         metric = oref.make_metric(oref.FBETA, k=5.0, m=float(m))
         _, mo = oref.predict_using_bc_with_0approx(Y, metric, 5, skip_tn=True, seed=13, max_iters=6, tolerance=-1.0)
         uo = np.asarray(mo["utilities"])
         print(f"{n}x{m} zipf={zipf} oracle {uo.tolist()}", flush=True)
-        for world in (2, 8):
-            settings = [1, 2, 4, 8, "auto"]
+        for world in worlds:
+            settings = sets
             ctx = mp.get_context("spawn")
             q = ctx.Queue()
             port = _free_port()

@@ -145,7 +145,16 @@ def test_bench_starts_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["value"] > 0
     assert j["comm"]["world_size"] == 2 and j["comm"]["backend"] == "gloo" and j["comm"]["all_reduce_bytes_per_sweep"] > 0
+    assert j["comm"]["world_size_seen"] == 2 and j["comm"]["ms_per_collective"] > 0 and j["comm"]["boundary_all_reduce_bytes"] == (2 * 30000 + 1) * 8
     assert j["config"]["rows_total"] == 200_000 and j["strong_scaling"]["rows_total"] == 100_000
+    sc = j["strong_scaling"]["comm"]
+    assert sc["world_size_seen"] == 2 and sc["ms_per_collective"] > 0
+    sp = sc["sharded_vs_oracle"]     # the public sharded call on the split matrix against the sequential oracle (rank 0)
+    print("bench sharded_vs_oracle:", sp)
+    # two shards of 50 K rows exchange three times per sweep (a part is not cut below 16 K rows): the first sweeps of a
+    # sharded run trail the sequential reference by about 1.8e-3 / exchanges at two predicted rows per label and close in
+    # by 3-4x per sweep (profiles/r03_shard_gpu_study.txt: the GPU engine = the checker engine's figures)
+    assert len(sp["abs_diff_by_sweep"]) == 2 and sp["abs_diff_by_sweep"][0] < 1e-3 and sp["abs_diff_by_sweep"][1] < 3e-4
     assert len(j["roofline"]["frac_by_sweep"]) == 3 and 0 < j["roofline"]["frac"] < 1
 
 

@@ -79,5 +79,25 @@ def test_sharded_bca_four_ranks_default_schedule():
     assert all(b > a - 1e-6 for a, b in zip(got, got[1:]))
 
 
+def _gpus():
+    import torch
+    return torch.cuda.device_count()     # counting devices does not initialise the GPU in this process
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="RCCL needs one GPU per rank (it refuses two ranks on one device) and this box has one: "
+                                        "the gloo tests above cover the same driver; this one runs on the multi-GPU node")
+def test_sharded_bca_two_ranks_rccl():
+    """The sharded call over backend "nccl" (= RCCL over xGMI), one GPU per rank: the default exchange schedule,
+    both ranks report the same trace, the last utility is the utility of the assembled prediction (asserted in the
+    script), every sweep within the documented distance of the sequential oracle."""
+    out = _run("bca_sharded_rehearsal.py", {"XC_REHEARSAL_BACKEND": "nccl"})
+    got, ref = _traces(out)
+    d = [abs(a - b) for a, b in zip(got, ref)]
+    print("two shards over RCCL", re.search(r"^exchanges.*$", out, re.M).group(0), "diff per sweep", d)
+    assert re.search(r"^backend nccl devices \[0, 1\]", out, re.M), out[-500:]
+    assert len(got) == len(ref) and d[-1] < 1e-5 and d[0] < 2e-4
+    assert all(b > a - 1e-6 for a, b in zip(got, got[1:]))
+
+
 def test_sharded_frank_wolfe_two_ranks_one_gpu():
     assert "sharded == single process: True" in _run("fw_sharded_rehearsal.py")
