@@ -592,7 +592,10 @@ int xc_coverage_product(int64_t n_k, const int32_t *pred_indices, const void *pr
  * The visiting order generated ON the GPU (csrc/xc_order_dev.hip): numpy's `Generator.shuffle` stream -- the
  * reference's `np.random.default_rng(seed)`, one array shuffled cumulatively once per sweep
  * (block_coordinate.py:413-419) -- with no host arithmetic and no host synchronisation per sweep: the PCG64
- * outputs by jump-ahead, the masked rejection by one wavefront, the Fisher-Yates swaps resolved in parallel.
+ * outputs by jump-ahead, the masked rejection settled for all batches of 8192 candidates at once in rounds (a batch's
+ * entering bound from what the batches before it kept in the previous round -- a workgroup per batch that waits only
+ * for lower-numbered workgroups, no grid barrier: the fixed point is the sequential walk, reached in ~18 rounds at
+ * 1 M rows), the Fisher-Yates swaps resolved in parallel.
  * Same permutation and same generator position as numpy (the wrapper checks both against numpy at first use).
  * ------------------------------------------------------------------------- */
 
@@ -605,9 +608,18 @@ int xc_order_dev_workspace_bytes(int64_t n, int64_t *bytes);
 int xc_order_dev_begin(void *workspace, const uint64_t *state_inc, int consumed, int64_t n, int32_t *order, void *stream);
 /* order_out <- one Generator.shuffle of order_in (int32[n] each, device, distinct); asynchronous on `stream`. */
 int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, int32_t *order_out, void *stream);
-/* out7_host = {failure flag (0: every shuffle so far is numpy's), 32-bit draws consumed, shuffles, shader cycles and
- * 100 MHz ticks of the last rejection walk, its rounds and batches}; blocks on `stream`. */
-int xc_order_dev_status(void *workspace, int64_t *out7_host, void *stream);
+/* out8_host = {failure flag (0: every shuffle so far is numpy's), 32-bit draws consumed, shuffles, shader cycles and
+ * 100 MHz ticks of the last rejection walk, its rounds and batches, walks redone by the one-workgroup fallback};
+ * blocks on `stream`. */
+int xc_order_dev_status(void *workspace, int64_t *out8_host, void *stream);
+/* Test knob: rounds the grid-wide rejection walk may take (0 = default, 64; 18-25 are needed).  With too few it gives up and
+ * the one-workgroup walk behind it redoes the shuffle: the same permutation, ~2 ms per million rows.  Negative: the
+ * one-workgroup walk only. */
+int xc_order_dev_set_rounds(int rounds);
+/* Diagnostics of the last rejection walk, per batch of 8192 candidates: {start, end (100 MHz ticks since the shuffle
+ * began), ticks waiting << 32 | ticks settling, rounds << 40 | settles << 24 | inner rounds}; out = NULL: only the number
+ * of batches.  Blocks on `stream`. */
+int xc_order_dev_walk_trace(void *workspace, int64_t n, int64_t *out, int64_t *batches_out, void *stream);
 
 /* ---------------------------------------------------------------------------
  * The ORDERED parallel sweep (csrc/xc_bca_ord.hip): the loop of block_coordinate.py:448-463 with thousands of

@@ -23,8 +23,34 @@ def test_device_orders_are_numpys(n):
             mine = gen.next().cpu().numpy()
             assert np.array_equal(ref, mine), (n, seed, s, int((ref != mine).sum()))
         gen.finish(sync_rng=True)
+        # the grid-wide rounds settled every walk themselves (no walk was left to the one-workgroup fallback)
+        assert gen.last_walk["fallbacks"] == 0 and 1 <= gen.last_walk["rounds"] <= 40, gen.last_walk
         # the Python generator is where numpy's own shuffles would have left it
         assert a.integers(0, 1 << 62, size=5).tolist() == b.integers(0, 1 << 62, size=5).tolist()
+
+
+@pytest.mark.parametrize("rounds", [1, 3])
+def test_device_orders_fall_back_to_the_one_workgroup_walk(rounds):
+    """Given too few rounds the grid-wide walk gives up: the one-workgroup walk behind it redoes the shuffle -- the
+    same permutations and generator position (the safety net of csrc/xc_order_dev.hip, never taken by default)."""
+    from xcolumns_amd import _device as D
+    from xcolumns_amd import _lib
+    from xcolumns_amd.utils import DeviceNumpyOrders
+    dev = D.require_gpu()
+    _lib.call("xc_order_dev_set_rounds", rounds)
+    try:
+        for n in (70_001, 300_000):
+            a, b = np.random.default_rng(11), np.random.default_rng(11)
+            ref = np.arange(n)
+            gen = DeviceNumpyOrders(b, n, dev, ahead=0)
+            for s in range(3):
+                a.shuffle(ref)
+                assert np.array_equal(ref, gen.next().cpu().numpy()), (n, s)
+            gen.finish(sync_rng=True)
+            assert gen.last_walk["fallbacks"] == 3, gen.last_walk
+            assert a.integers(0, 1 << 62, size=5).tolist() == b.integers(0, 1 << 62, size=5).tolist()
+    finally:
+        _lib.call("xc_order_dev_set_rounds", 0)
 
 
 def test_device_orders_with_a_buffered_half_and_many_sweeps():
@@ -87,8 +113,8 @@ def test_device_orders_time_and_api_use(oref):
     torch.cuda.synchronize()
     print("device order generator: %.3f ms per 1M-row order" % ((time.perf_counter() - t0) * 100))
     gen.finish()
-    print("  the rejection walk (one wavefront): %d cycles in %.1f us = %.0f MHz" % (
-        gen.last_walk["cycles"], gen.last_walk["us"], gen.last_walk["cycles"] / max(1e-9, gen.last_walk["us"])), gen.last_walk)
+    print("  the rejection walk (grid-wide rounds): %.1f us, %d rounds" % (gen.last_walk["us"], gen.last_walk["rounds"]), gen.last_walk)
+    assert gen.last_walk["fallbacks"] == 0
     # beside a kernel that keeps the GPU busy (the product's situation: the sweeps run meanwhile)
     gen = DeviceNumpyOrders(np.random.default_rng(1), 1_000_000, dev, ahead=2)
     a = torch.rand(8192, 8192, device=dev)
@@ -101,8 +127,8 @@ def test_device_orders_time_and_api_use(oref):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 100
     gen.finish()
-    print("  beside elementwise kernels on the main stream: %.3f ms per order + 4 kernels; walk %d cycles in %.1f us = %.0f MHz" % (
-        dt, gen.last_walk["cycles"], gen.last_walk["us"], gen.last_walk["cycles"] / max(1e-9, gen.last_walk["us"])))
+    print("  beside elementwise kernels on the main stream: %.3f ms per order + 4 kernels; walk %.1f us, %d rounds" % (
+        dt, gen.last_walk["us"], gen.last_walk["rounds"]))
     Y = make_csr(120_000, 40_000, 30, seed=8)
     _, m1 = f(Y, 5, seed=3, max_iters=3, tolerance=-1.0, return_meta=True, bca_waves=1)
     os.environ["XCOLUMNS_ORDER_DEVICE"] = "0"

@@ -143,6 +143,8 @@ SIGNATURES = {
     "xc_order_dev_begin": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "xc_order_dev_shuffle": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "xc_order_dev_status": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
+    "xc_order_dev_set_rounds": (c_int, [c_int]),
+    "xc_order_dev_walk_trace": (c_int, [c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "xc_bca_ord_window": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "xc_bca_ord_workspace_bytes": (c_int, [c_int64, c_int64, c_int, c_int, POINTER(c_int64)]),
     "xc_bca_ord_sweep": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -667,12 +667,15 @@ class BcaCsrEngine:
             for dd in self._ord_dirs.values():
                 dd["ws"].zero_()
             self._ord_epoch = 1 << 20
+        from .utils import order_generators_fence
+        order_generators_fence(True)     # no visiting-order walk is dispatched into the grid barrier of this kernel
         _lib.call("xc_bca_ord_sweep", D.ptr(d["ws"]), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta),
                   D.ptr(self.sel), D.ptr(self.orphans), self.k, c.m, D.ptr(self.tpfp), D.ptr(self.s_entry), D.ptr(d["lab_dir"]),
                   d["total_cap"], D.ptr(d["hot_labels"]), d["n_hot"], self._ord_wg, self._ord_rpw, ctypes.byref(self.gain_metric),
                   int(self.maximize), int(self.skip_tn), ctypes.c_uint32(self._ord_epoch), D.ptr(self.changed), status,
                   D.stream())
+        order_generators_fence(False)
         self._ord_epoch += 1 << 20
         done, err = int(status[0]), int(status[1])
         self.ordered_stats = {"iterations": int(status[2]), "windows": int(status[3]), "done": done, "error": err,
@@ -927,15 +930,15 @@ class _OrderWorkers:
         return done
 
 
-_DEVICE_WALK_NS_PER_ROW = 2.7     # csrc/xc_order_dev.hip: per row and sweep of a 20-sweep call at 1 M rows, measured (profiles/r03_api_call_timing.txt)
+_DEVICE_WALK_NS_PER_ROW = 0.75     # the device generator: 0.72 ms per 1 M-row order (grid-wide rejection walk, csrc/xc_order_dev.hip)
 _order_choice = None
 
 
 def _orders_on_device() -> bool:
     """Where numpy's visiting-order stream is generated for large matrices: XCOLUMNS_ORDER_DEVICE=1 / 0 forces the GPU
     / the host's two worker threads; by default whichever is faster on THIS machine -- the device generator takes the
-    same 2.7 ns per row everywhere, the host's sequential walk 1.3 ns per row on a fast idle core (then the call is
-    nearly kernel-bound) and 4 ns and more on a slow or busy one (measured once per process on 256 K rows)."""
+    same 0.75 ns per row everywhere, the host's sequential walk 1.3 ns per row on a fast idle core and 4 ns and more on
+    a slow or busy one (measured once per process on 256 K rows): in practice the device, unless it is not usable."""
     global _order_choice
     env = os.environ.get("XCOLUMNS_ORDER_DEVICE")
     if env is not None:
@@ -978,8 +981,12 @@ class _OrderSource:
     runs; ``next()`` makes the compute stream wait for the copy only.  Same stream, same orders -- the loop just
     stops waiting for them."""
 
-    def __init__(self, n: int, seed, shuffle: bool, backend: str, dev, prefetch: Optional[bool] = None):
+    def __init__(self, n: int, seed, shuffle: bool, backend: str, dev, prefetch: Optional[bool] = None,
+                 limit: Optional[int] = None):
         self.n, self.shuffle, self.backend, self.dev = n, shuffle, backend, dev
+        # orders the run can ask for at most (max_iters): nothing is generated ahead beyond them, so a run that uses
+        # them all finds nothing in flight when it closes the source (3 ms per call at 1 M rows otherwise)
+        self.limit = (1 << 62) if limit is None else max(0, int(limit))
         if backend not in ("numpy", "device"):
             raise ValueError("order_backend must be 'numpy' or 'device'")
         self.rng = np.random.default_rng(seed)       # :413
@@ -999,7 +1006,7 @@ class _OrderSource:
         if backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS and _orders_on_device():
             from .utils import DeviceNumpyOrders
             if DeviceNumpyOrders.usable(dev):
-                self._devgen = DeviceNumpyOrders(self.rng, n, dev)
+                self._devgen = DeviceNumpyOrders(self.rng, n, dev, limit=self.limit)
                 self._fast = None
         if backend == "device" and shuffle:
             self.gen = torch.Generator(device=dev)
@@ -1056,7 +1063,9 @@ class _OrderSource:
 
     def _produce_draws(self):
         try:
-            while not self._stop.is_set():
+            made = 0
+            while not self._stop.is_set() and made < self.limit:
+                made += 1
                 t0 = _time.perf_counter()
                 js = self._fast.draws()
                 if self._trace is not None:
@@ -1084,7 +1093,7 @@ class _OrderSource:
             pinned = res[key]
             done = [None] * slots
             i = 0
-            while not self._stop.is_set():
+            while not self._stop.is_set() and i < self.limit:
                 slot = i % slots
                 if done[slot] is not None:
                     done[slot].synchronize()          # its previous copy has left the pinned buffer
@@ -1351,7 +1360,7 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
     # the host starts walking the visiting orders NOW: the first ones are ready by the time the matrix is uploaded,
     # packed and its initial prediction made (the walk is what bounds a call on a resident matrix: ~1.3 ms per
     # 1 M-row order behind a 0.5 ms sweep)
-    orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev)
+    orders = _OrderSource(n_u, seed, shuffle_order, order_backend, dev, limit=max_iters)
     try:
         csr = D.as_device_csr(y_proba, dev)
         eng = BcaCsrEngine(csr, k, gain_spec, utility_spec, maximize=maximize, skip_tn=skip_tn,

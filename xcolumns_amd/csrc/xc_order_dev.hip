@@ -6,14 +6,19 @@
 // rejection on the 32-bit halves of the PCG64 (XSL-RR 128/64) outputs (numpy/random/_generator.pyx `_shuffle_raw`,
 // src/distributions/distributions.c `random_interval`, src/pcg64/pcg64.h `pcg64_next32`).  On the host that walk is
 // 2-3 ms per million rows (csrc/xc_order.hip) behind a 0.5 ms sweep kernel.  Here the same permutation and the same
-// generator position come out of four device steps, no host arithmetic and no host synchronisation per sweep:
+// generator position come out of four device steps, no host arithmetic and no host synchronisation per sweep (0.7 ms per
+// million rows; 2.2 ms with the rejection walked by one workgroup, the form of this file until the grid-wide walk):
 //
 //   raw     every thread jumps the 128-bit LCG ahead to its own outputs (state_k = A^k state_0 + C_k) and writes
 //           their 32-bit halves: the candidate stream, in order;
-//   filter  ONE wavefront walks the candidates 512 at a time and keeps those the rejection loop keeps: a candidate
-//           <= i - 512 is kept and one > i is dropped whatever the others in its group do; the few in between are
-//           settled one by one.  It leaves the partners j_t of the steps t = 0 .. n-2 (i_t = n-1-t) and the number of
-//           candidates consumed (the generator's position for the next shuffle);
+//   filter  which candidates does the rejection loop keep?  A candidate is kept iff it is <= the bound i at the time, and i
+//           drops by one per kept candidate: a sequential recurrence.  One workgroup per batch of 8192 candidates, all
+//           batches of the shuffle in ONE launch, in rounds: a batch is settled exactly from its entering bound (a candidate
+//           <= i - 512 is kept and one > i dropped whatever the others of its group do; the few in between one by one),
+//           and its entering bound is (n - 1) - what the batches before it kept in the previous round -- first guess: the
+//           expectation.  The fixed point is the sequential walk; ~17 rounds at 1 M rows; no grid barrier (a workgroup
+//           waits only for lower-numbered ones).  It leaves the partners j_t of the steps t = 0 .. n-2 (i_t = n-1-t) and
+//           the number of candidates consumed (the generator's position for the next shuffle);
 //   lists   per position q the steps whose partner is q (a linked list, atomicExch on a head);
 //   resolve the value at position i_t before step t is the value the latest EARLIER step with partner i_t moved there
 //           (or the old array's); these "who wrote it last" links form short chains, followed by pointer jumping; then
@@ -38,7 +43,16 @@ typedef unsigned __int128 u128;
 #define XC_OG_BATCHES 10   /* batches (of 64 planes) the last walk left records for */
 #define XC_OG_FIRST 11     /* raw index of the last walk's first candidate (0 or 1) */
 #define XC_OG_ROUNDS 12    /* rounds of the last walk (diagnostics) */
-#define XC_OG_WORDS 16
+#define XC_OG_T0 13        /* 100 MHz tick at which the last shuffle began (raw kernel) */
+#define XC_OG_FALLBACK 14  /* walks the grid-wide kernel did not settle and the one-workgroup walk redid */
+#define XC_OG_EPOCH 15     /* shuffle number the grid-wide walk tags its publications with */
+// staged by the grid-wide walk, committed behind it (its late workgroups still read the words above)
+#define XC_OG_NEXT_CONSUMED 16
+#define XC_OG_NEXT_FLAG 17
+#define XC_OG_NEXT_ROUNDS 18
+#define XC_OG_UNSETTLED 19 /* != 0: the grid-wide walk gave up (rounds exhausted / a wait timed out): the one-workgroup walk redoes it */
+#define XC_OG_ABORT 20
+#define XC_OG_WORDS 24
 
 __device__ __forceinline__ u128 og_mult() { return ((u128)2549297995355413924ULL << 64) | (u128)4865540595714422341ULL; }
 
@@ -50,9 +64,16 @@ __device__ __forceinline__ unsigned long long og_output(u128 s) { // XSL-RR of a
 }
 
 // raw[r] = draw (first + r) of the stream, r < count, where first = consumed & ~1 (the filter skips one if consumed is odd)
-__global__ __launch_bounds__(256) void og_raw_kernel(const unsigned long long *hdr, unsigned *raw, long long count) {
+__global__ __launch_bounds__(256) void og_raw_kernel(unsigned long long *hdr, unsigned *raw, long long count) {
     constexpr int PER = 8; // outputs per thread
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) { // the shuffle begins: what the walk behind this kernel counts on
+        hdr[XC_OG_T0] = __builtin_amdgcn_s_memrealtime();
+        hdr[XC_OG_EPOCH] += 1ull;
+        hdr[XC_OG_UNSETTLED] = 0ull;
+        hdr[XC_OG_ABORT] = 0ull;
+        hdr[XC_OG_NEXT_FLAG] = 0ull;
+    }
     const long long r0 = g * PER * 2;
     if (r0 >= count) return;
     const u128 inc = ((u128)hdr[XC_OG_INC_HI] << 64) | hdr[XC_OG_INC_LO];
@@ -149,6 +170,86 @@ __device__ __forceinline__ unsigned long long og_plane64(unsigned x, unsigned i)
     return a;
 }
 
+// Settle ONE plane of 64 candidates (u: LDS) from its exact entering bound i, whatever the mask does in it: the kept mask,
+// and whether the mask followed the bound through the plane (`follows`: og_compact_kernel's one_by_one).  `used` grows by
+// the candidates consumed (fewer than 64 only where the walk ends).
+__device__ __forceinline__ unsigned long long og_one_plane(const unsigned *u, int lane, long long steps, long long &got, unsigned &i, int &used,
+                                                           unsigned &follows) {
+    const unsigned mp = og_mask(i);
+    const unsigned lowp = (mp >> 1) + 1u;
+    unsigned long long a;
+    follows = 0u;
+    if (i >= lowp + 64u && steps - got > 64) {
+        a = og_plane64(u[lane] & mp, i);
+        const unsigned kept = (unsigned)__popcll(a);
+        got += kept;
+        i -= kept;
+        used += 64;
+    } else if (lowp >= 128u && i >= 64u && steps - got > 64) {
+        // the plane in which the bound leaves its mask (once: the next mask holds for lowp / 2 >= 64 steps): settled as if
+        // the mask held, which is right up to the candidate whose keeping takes the bound to lowp - 1; the candidates
+        // behind it are settled from there with the next mask
+        const unsigned xv = u[lane];
+        const unsigned need = i - lowp + 1u; // candidates kept under this mask before the bound leaves it
+        a = og_plane64(xv & mp, i);
+        if ((unsigned)__popcll(a) >= need) {
+            unsigned long long bts = a;
+            for (unsigned q = 1u; q < need; ++q) bts &= bts - 1ull;
+            const int e_star = __builtin_ctzll(bts); // the candidate that takes the bound to lowp - 1
+            a &= (2ull << e_star) - 1ull;
+            const unsigned x2 = lane > e_star ? (xv & (mp >> 1)) : 0xFFFFFFFFu;
+            a |= og_plane64(x2, lowp - 1u);
+        }
+        follows = 1u;
+        const unsigned kept = (unsigned)__popcll(a);
+        got += kept;
+        i -= kept;
+        used += 64;
+    } else { // the last steps of the walk (masks below 128, or its end): one candidate at a time
+        a = 0ull;
+        int e = 0;
+        const unsigned xv = u[lane]; // the plane in a register: a lane read per step, not an LDS round trip
+        for (; e < 64 && got < steps; ++e) {
+            const unsigned ue = (unsigned)__builtin_amdgcn_readlane((int)xv, e);
+            const unsigned xx = ue & og_mask(i);
+            if (__builtin_amdgcn_readfirstlane((int)(xx <= i))) {
+                a |= 1ull << e;
+                ++got;
+                --i;
+            }
+        }
+        follows = 1u;
+        used += e;
+    }
+    i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+    got = og_uni64(got);
+    return a;
+}
+
+// Settle one group plane by plane: the path of the groups in which the rejection mask changes or the walk ends, and of the
+// sequential tail (og_tail_batch).
+__device__ __forceinline__ void og_group_planes(const unsigned *u, OgRec *rec, int lane, long long steps, long long &got, unsigned &i,
+                                                int &used) {
+    used = 0;
+#pragma unroll 1
+    for (int p = 0; p < XC_OG_PLANES; ++p) {
+        if (got < steps) {
+            const unsigned i_begin = i;
+            unsigned follows = 0u;
+            const unsigned long long a = og_one_plane(u + p * 64, lane, steps, got, i, used, follows);
+            if (lane == p) {
+                rec[p].bound = i_begin;
+                rec[p].one_by_one = follows;
+                rec[p].kept = a;
+            }
+        } else if (lane == p) {
+            rec[p].bound = 0u;
+            rec[p].one_by_one = 0u;
+            rec[p].kept = 0ull;
+        }
+    }
+}
+
 // Settle one group of 512 candidates (u: LDS) that begins at bound i with `got` steps done: the plane records (rec: LDS),
 // the candidates consumed (`used` < 512 only where the walk ends) and the bound / step count after it.
 __device__ __forceinline__ void og_group(const unsigned *u, OgRec *rec, int lane, long long steps, long long &got, unsigned &i,
@@ -243,63 +344,144 @@ __device__ __forceinline__ void og_group(const unsigned *u, OgRec *rec, int lane
         return;
     }
     // the mask changes within the next 512 steps, or the walk ends (or has ended): plane by plane
-    used = 0;
-#pragma unroll
-    for (int p = 0; p < XC_OG_PLANES; ++p) {
-        if (got < steps) {
-            const unsigned mp = og_mask(i);
-            const unsigned lowp = (mp >> 1) + 1u;
-            if (i >= lowp + 64u && steps - got > 64) {
-                const unsigned long long a = og_plane64(u[p * 64 + lane] & mp, i);
-                if (lane == p) {
-                    rec[p].bound = i;
-                    rec[p].one_by_one = 0u;
-                    rec[p].kept = a;
-                }
-                const unsigned kept = (unsigned)__popcll(a);
-                got += kept;
-                i -= kept;
-                used += 64;
-            } else { // the plane that holds the change of the mask, or the end of the walk: one candidate at a time
-                const unsigned i_begin = i;
-                unsigned long long a = 0ull;
-                int e = 0;
-                for (; e < 64 && got < steps; ++e) {
-                    const unsigned ue = (unsigned)__builtin_amdgcn_readfirstlane((int)u[p * 64 + e]);
-                    const unsigned xx = ue & og_mask(i);
-                    if (__builtin_amdgcn_readfirstlane((int)(xx <= i))) {
-                        a |= 1ull << e;
-                        ++got;
-                        --i;
-                    }
-                }
-                if (lane == p) {
-                    rec[p].bound = i_begin;
-                    rec[p].one_by_one = 1u;
-                    rec[p].kept = a;
-                }
-                used += e;
-            }
-            i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
-            got = og_uni64(got);
-        } else if (lane == p) {
-            rec[p].bound = 0u;
-            rec[p].one_by_one = 0u;
-            rec[p].kept = 0ull;
+    og_group_planes(u, rec, lane, steps, got, i, used);
+}
+
+// LDS of a walking workgroup
+struct OgShared {
+    unsigned raw[XC_OG_WAVES * XC_OG_GROUP]; // the batch: 16 groups
+    OgRec rec[XC_OG_WAVES * XC_OG_PLANES];
+    unsigned kept[XC_OG_WAVES];              // candidates the group keeps, given its entering bound
+    int used[XC_OG_WAVES];
+    unsigned enter[XC_OG_WAVES + 1];         // entering bounds of this round (and of the next batch)
+    unsigned kind[XC_OG_WAVES];
+    int again;
+};
+
+// Settle the batch in S.raw from its (exact) entering bound: S.enter[] must hold a guess of the 16 entering bounds with
+// S.enter[0] = the batch's; rounds until no bound moves.  Leaves S.rec / S.kind / S.used / S.kept and the exit bound in
+// S.enter[16].  All 1024 threads call it; returns the rounds it took.
+__device__ __forceinline__ int og_batch(OgShared &S, long long n, long long steps) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned i_batch = S.enter[0];
+    int rounds = 0;
+    for (;;) {
+        unsigned i = S.enter[wv];
+        long long got = (long long)(n - 1) - (long long)i;
+        int used = 0;
+        const unsigned i_in = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+        unsigned kind = 0u;
+        og_group(S.raw + wv * XC_OG_GROUP, S.rec + wv * XC_OG_PLANES, lane, steps, got, i, used, kind);
+        if (lane == 0) {
+            S.kept[wv] = i_in - i;
+            S.used[wv] = used;
+            S.kind[wv] = kind;
         }
+        if (threadIdx.x == 0) S.again = 0;
+        __syncthreads();
+        if (wv == 0) { // new entering bounds from the kept counts (lane g: group g); has any moved?
+            unsigned kq = lane < XC_OG_WAVES ? S.kept[lane] : 0u;
+            unsigned incl = kq; // inclusive prefix over the lanes
+#pragma unroll
+            for (int o = 1; o < XC_OG_WAVES; o <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, o, XC_WAVE);
+                if (lane >= o) incl += up;
+            }
+            const unsigned enter = i_batch - (incl - kq);
+            const bool moved = lane < XC_OG_WAVES && S.enter[lane] != enter;
+            if (lane < XC_OG_WAVES) S.enter[lane] = enter;
+            if (lane == XC_OG_WAVES - 1) S.enter[XC_OG_WAVES] = enter - kq;
+            const unsigned long long mv = __ballot(moved);
+            if (lane == 0) S.again = mv != 0ull ? 1 : 0;
+        }
+        ++rounds;
+        __syncthreads();
+        if (S.again == 0) break; // every group was settled from its true entering bound
+    }
+    return rounds;
+}
+
+// the settled batch's plane records -> recs[batch]
+__device__ __forceinline__ void og_store_records(const OgShared &S, OgRec *recs, long long batch) {
+    if (threadIdx.x < XC_OG_WAVES * XC_OG_PLANES) {
+        OgRec rc = S.rec[threadIdx.x];
+        const int g = threadIdx.x / XC_OG_PLANES;
+        if ((S.kind[g] & 15u) == XC_OG_KIND_LEAN) { // one record for the group, in its first plane's slot
+            rc.bound = S.enter[g];
+            rc.one_by_one = 2u;
+            rc.kept = (unsigned long long)(S.kind[g] >> 4); // extras: count (4 bits), then 9-bit positions
+        }
+        recs[batch * (XC_OG_WAVES * XC_OG_PLANES) + threadIdx.x] = rc;
     }
 }
 
-__global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long long *hdr, const unsigned *raw, long long count, long long n,
-                                                                    OgRec *recs) {
+// The expected bound t candidates after bound i0: while the mask holds, (i + 1) decays like exp(-t / (mask + 1)).
+__device__ __forceinline__ unsigned og_expected_from(unsigned i0, double t) {
+    double i = (double)i0;
+    while (t > 0.0 && i >= 1.0) {
+        const unsigned m = og_mask((unsigned)i);
+        const double range = (double)m + 1.0, low = (double)(m >> 1) + 1.0;
+        const double t_plane = range * ::log((i + 1.0) / low); // candidates until the bound leaves this mask
+        if (t < t_plane) {
+            i = (i + 1.0) * ::exp(-t / range) - 1.0;
+            break;
+        }
+        t -= t_plane;
+        i = low - 1.0;
+    }
+    return i > 0.0 ? (unsigned)i : 0u;
+}
+
+// first guess of a batch's 16 entering bounds from its own: the expected bounds (a change of the mask inside the batch included)
+__device__ __forceinline__ void og_guess_within(OgShared &S, unsigned i_batch) {
+    if (threadIdx.x <= XC_OG_WAVES) S.enter[threadIdx.x] = threadIdx.x == 0 ? i_batch : og_expected_from(i_batch, (double)(XC_OG_GROUP * threadIdx.x));
+}
+
+// The batch in S.raw settled by ONE wavefront, plane after plane, from its (exact) entering bound: the tail of the walk
+// (bounds below a batch's worth of candidates: the mask changes every few hundred steps and the walk ends -- guesses of the
+// groups' entering bounds are worth nothing there, and og_group's own path for such groups is the slow one).  Leaves what
+// og_batch leaves.  All threads call it.
+__device__ __forceinline__ void og_tail_batch(OgShared &S, long long n, long long steps, unsigned bound) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ unsigned s_raw[XC_OG_WAVES * XC_OG_GROUP];      // the batch: 16 groups
-    __shared__ OgRec s_rec[XC_OG_WAVES * XC_OG_PLANES];
-    __shared__ unsigned s_kept[XC_OG_WAVES];                   // candidates the group keeps, given its entering bound
-    __shared__ int s_used[XC_OG_WAVES];
-    __shared__ unsigned s_enter[XC_OG_WAVES + 1];              // entering bounds of this round (and of the next batch)
-    __shared__ int s_again;
-    __shared__ unsigned s_kind[XC_OG_WAVES];
+    if (wv == 0) {
+        unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)bound);
+        long long got = (long long)(n - 1) - (long long)i;
+        for (int g = 0; g < XC_OG_WAVES; ++g) {
+            const unsigned i_in = i;
+            int used = 0;
+            og_group_planes(S.raw + g * XC_OG_GROUP, S.rec + g * XC_OG_PLANES, lane, steps, got, i, used);
+            if (lane == 0) {
+                S.enter[g] = i_in;
+                S.kept[g] = i_in - i;
+                S.used[g] = used;
+                S.kind[g] = XC_OG_KIND_PLANES;
+            }
+        }
+        if (lane == 0) S.enter[XC_OG_WAVES] = i;
+    }
+    __syncthreads();
+}
+
+// The one-workgroup walk: batch after batch.  Behind the grid-wide walk below it is the safety net: it commits what that
+// one staged and returns, unless the grid-wide walk gave up -- then it walks the shuffle itself.
+__global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long long *hdr, const unsigned *raw, long long count, long long n,
+                                                                    OgRec *recs, int behind_grid, unsigned grid_batches) {
+    if (behind_grid && hdr[XC_OG_UNSETTLED] == 0ull) {
+        if (threadIdx.x == 0) { // commit the grid-wide walk's result (its workgroups have all left)
+            const unsigned long long first = hdr[XC_OG_CONSUMED] & 1ull;
+            if (hdr[XC_OG_NEXT_FLAG] != 0ull) hdr[XC_OG_FLAG] = hdr[XC_OG_NEXT_FLAG];
+            hdr[XC_OG_BATCHES] = (unsigned long long)grid_batches;
+            hdr[XC_OG_FIRST] = first;
+            hdr[XC_OG_CONSUMED] = (hdr[XC_OG_CONSUMED] & ~1ull) + hdr[XC_OG_NEXT_CONSUMED];
+            hdr[XC_OG_SHUFFLES] += 1ull;
+            hdr[XC_OG_TICKS] = __builtin_amdgcn_s_memrealtime() - hdr[XC_OG_T0];
+            hdr[XC_OG_CYCLES] = 24ull * hdr[XC_OG_TICKS]; // nominal (many workgroups)
+            hdr[XC_OG_ROUNDS] = hdr[XC_OG_NEXT_ROUNDS];
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ OgShared S;
     const long long first = (long long)__builtin_amdgcn_readfirstlane((int)(hdr[XC_OG_CONSUMED] & 1ull)); // odd: the low half of that output is spent
     const long long steps = n - 1;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -320,68 +502,26 @@ __global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long
             break;
         }
 #pragma unroll
-        for (int p = 0; p < XC_OG_PLANES; ++p) s_raw[wv * XC_OG_GROUP + p * 64 + lane] = nxt[p];
+        for (int p = 0; p < XC_OG_PLANES; ++p) S.raw[wv * XC_OG_GROUP + p * 64 + lane] = nxt[p];
         {   // the next batch's candidates, in flight during the rounds
             const long long b1 = base + XC_OG_WAVES * XC_OG_GROUP + (long long)wv * XC_OG_GROUP;
 #pragma unroll
             for (int p = 0; p < XC_OG_PLANES; ++p) nxt[p] = b1 + p * 64 + lane < count ? raw[b1 + p * 64 + lane] : 0u;
         }
-        // first guess of the entering bounds: the expected number of kept candidates per group, (i + 1) / (mask + 1) each
-        if (threadIdx.x <= XC_OG_WAVES) {
-            const double p_keep = ((double)i_batch + 1.0) / ((double)og_mask(i_batch) + 1.0);
-            const long long drop = (long long)(p_keep * XC_OG_GROUP * threadIdx.x);
-            s_enter[threadIdx.x] = drop < (long long)i_batch ? i_batch - (unsigned)drop : 0u;
-        }
-        if (threadIdx.x == 0) s_enter[0] = i_batch;
-        __syncthreads();
-        for (;;) {
-            unsigned i = s_enter[wv];
-            long long got = (long long)(n - 1) - (long long)i;
-            int used = 0;
-            const unsigned i_in = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
-            unsigned kind = 0u;
-            og_group(s_raw + wv * XC_OG_GROUP, s_rec + wv * XC_OG_PLANES, lane, steps, got, i, used, kind);
-            if (lane == 0) {
-                s_kept[wv] = i_in - i;
-                s_used[wv] = used;
-                s_kind[wv] = kind;
-            }
-            if (threadIdx.x == 0) s_again = 0;
-            __syncthreads();
-            if (wv == 0) { // new entering bounds from the kept counts (lane g: group g); has any moved?
-                unsigned kq = lane < XC_OG_WAVES ? s_kept[lane] : 0u;
-                unsigned incl = kq; // inclusive prefix over the lanes
-#pragma unroll
-                for (int o = 1; o < XC_OG_WAVES; o <<= 1) {
-                    const unsigned up = (unsigned)__shfl_up((int)incl, o, XC_WAVE);
-                    if (lane >= o) incl += up;
-                }
-                const unsigned enter = i_batch - (incl - kq);
-                const bool moved = lane < XC_OG_WAVES && s_enter[lane] != enter;
-                if (lane < XC_OG_WAVES) s_enter[lane] = enter;
-                if (lane == XC_OG_WAVES - 1) s_enter[XC_OG_WAVES] = enter - kq;
-                const unsigned long long mv = __ballot(moved);
-                if (lane == 0) s_again = mv != 0ull ? 1 : 0;
-            }
+        if (i_batch <= (unsigned)(XC_OG_WAVES * XC_OG_GROUP)) { // the tail: one wavefront, plane after plane
+            og_tail_batch(S, n, steps, i_batch);
             ++rounds;
+        } else {
+            og_guess_within(S, i_batch);
             __syncthreads();
-            if (s_again == 0) break; // every group was settled from its true entering bound
+            rounds += og_batch(S, n, steps);
         }
         // the batch's records; candidates consumed (only the group in which the walk ends consumes fewer than 512)
-        if (threadIdx.x < XC_OG_WAVES * XC_OG_PLANES) {
-            OgRec rc = s_rec[threadIdx.x];
-            const int g = threadIdx.x / XC_OG_PLANES;
-            if ((s_kind[g] & 15u) == XC_OG_KIND_LEAN) { // one record for the group, in its first plane's slot
-                rc.bound = s_enter[g];
-                rc.one_by_one = 2u;
-                rc.kept = (unsigned long long)(s_kind[g] >> 4); // extras: count (4 bits), then 9-bit positions
-            }
-            recs[batch * (XC_OG_WAVES * XC_OG_PLANES) + threadIdx.x] = rc;
-        }
+        og_store_records(S, recs, batch);
         long long use = 0;
-        for (int g = 0; g < XC_OG_WAVES; ++g) use += s_used[g];
+        for (int g = 0; g < XC_OG_WAVES; ++g) use += S.used[g];
         consumed = base + use;
-        i_batch = s_enter[XC_OG_WAVES];
+        i_batch = S.enter[XC_OG_WAVES];
         ++batch;
         __syncthreads();
     }
@@ -394,7 +534,185 @@ __global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long
         hdr[XC_OG_CYCLES] = __builtin_amdgcn_s_memtime() - c0;
         hdr[XC_OG_TICKS] = __builtin_amdgcn_s_memrealtime() - r0;
         hdr[XC_OG_ROUNDS] = (unsigned long long)rounds;
+        if (behind_grid) hdr[XC_OG_FALLBACK] += 1ull;
+    }
+}
 
+// ---- the same walk, grid-wide ---------------------------------------------------------------------------------------
+// One workgroup per BATCH (16 groups, 8192 candidates), all batches of the shuffle in one launch.  A batch settled from
+// its entering bound keeps F_b(bound) candidates (og_batch: exact).  Round r of workgroup b:
+//     bound_b(r) = (n - 1) - sum over the batches h < b of what they kept in round r - 1,
+// first guess (round 0): the expected bound, in closed form per mask ((i + 1) decays like exp(-t / (mask + 1))).  Batch 0 is
+// exact from the start and the error of the guesses dies out like x^k / k! (a batch's kept count depends on its entering
+// bound only through the candidates between the guess and the truth: 8192 / 2^20 of a unit per unit at 1 M rows): 18 rounds
+// at 1 M rows, 25 at 10 M, ~7 settles per batch (tests/studies/walk_rounds.c) -- against 172 batches one after the other.
+//
+// No grid barrier: workgroup b reads only what workgroups h < b published, from a history hist[round][workgroup] of
+// 64-bit words {shuffle number, kept} written once each -- it never waits for a workgroup that the dispatcher starts after
+// it (workgroups start in index order: the assumption of every decoupled look-back scan), so the kernel needs no
+// co-residency and cannot deadlock against other kernels.  Workgroup b is FINAL in round r when every h < b published the
+// same count in rounds r - 1 and r - 2: then all bounds below b are where they were a round ago, so are their counts, and by
+// induction they never move again; it settles from its bound, fills the rest of its history with that count and leaves.
+// The workgroup in which the walk ends stages the generator's new position; og_walk_kernel (one workgroup, behind this
+// launch) commits it -- or, if this kernel gave up (rounds exhausted, a wait that timed out: never observed), walks the
+// shuffle itself: the result is exact whatever happens here.
+#define XC_OG_HIST_ROUNDS 64
+#define XC_OG_SPIN_LIMIT (1u << 21) /* polls of ~2 us each */
+
+__device__ __forceinline__ unsigned long long og_ld64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void og_st64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_grid_kernel(unsigned long long *hdr, const unsigned *raw, long long n, OgRec *recs,
+                                                                         unsigned long long *hist, int max_rounds,
+                                                                         unsigned long long *dbg) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_wait = 0ull, t_settle = 0ull;
+    int settles = 0;
+    __shared__ OgShared S;
+    __shared__ unsigned s_sum[1], s_same[1], s_bad[1];
+    __shared__ unsigned s_prev_kept[XC_OG_WAVES];
+    const unsigned b = blockIdx.x, nb = gridDim.x;
+    const long long first = (long long)__builtin_amdgcn_readfirstlane((int)(hdr[XC_OG_CONSUMED] & 1ull));
+    const unsigned long long epoch = hdr[XC_OG_EPOCH] << 32;
+    const long long steps = n - 1;
+    {   // this batch's candidates (whole batches only: the host sizes the grid so)
+        const long long b0 = first + ((long long)b * XC_OG_WAVES + wv) * XC_OG_GROUP;
+#pragma unroll
+        for (int p = 0; p < XC_OG_PLANES; ++p) S.raw[wv * XC_OG_GROUP + p * 64 + lane] = raw[b0 + p * 64 + lane];
+    }
+    unsigned bound_prev = 0xFFFFFFFFu, kept_total = 0u, last_publish = 0x80000000u;
+    int inner = 0, r = 0;
+    bool gave_up = false, have_prev = false;
+    for (;; ++r) {
+        // -- this round's entering bound, and whether the batches before are at rest
+        unsigned bound;
+        bool final_now;
+        if (b == 0u) {
+            bound = (unsigned)(n - 1);
+            final_now = true;
+        } else if (r == 0) {
+            bound = og_expected_from((unsigned)(n - 1), (double)b * (XC_OG_WAVES * XC_OG_GROUP));
+            final_now = false;
+        } else {
+            // ONE wavefront reads what the batches before kept in round r - 1 and (from round 2 on) in round r - 2, waiting
+            // for the words to carry this shuffle's tag; the others wait at the barrier (thousands of polling lanes starve
+            // the memory system: 0.5 ms per round with all 1024 threads polling)
+            const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+            if (wv == 0) {
+                unsigned sum = 0u, same = 1u, bad = 0u;
+                for (unsigned h0 = 0u; h0 < b && bad == 0u; h0 += 64u) {
+                    const unsigned h = h0 + (unsigned)lane;
+                    const bool act = h < b;
+                    unsigned long long w1 = 0ull, w2 = 0ull;
+                    bool ok1 = !act, ok2 = !act || r < 2;
+                    unsigned spins = 0u;
+                    for (;;) {
+                        if (!ok1) {
+                            w1 = og_ld64(hist + (size_t)(r - 1) * nb + h);
+                            ok1 = (w1 & 0xFFFFFFFF00000000ull) == epoch;
+                        }
+                        if (!ok2) {
+                            w2 = og_ld64(hist + (size_t)(r - 2) * nb + h);
+                            ok2 = (w2 & 0xFFFFFFFF00000000ull) == epoch;
+                        }
+                        if (__ballot(!(ok1 && ok2)) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(32);
+                        if ((++spins & 255u) == 0u && (spins > XC_OG_SPIN_LIMIT || og_ld64(hdr + XC_OG_ABORT) != 0ull)) {
+                            bad = 1u;
+                            break;
+                        }
+                    }
+                    if (act && bad == 0u) { // low word: exact flag (bit 31) | candidates kept
+                        sum += (unsigned)w1 & 0x7FFFFFFFu;
+                        same &= (unsigned)w1 >> 31; // an estimate (a batch of the tail that is not final yet) settles nothing
+                        if (r >= 2) same &= (unsigned)w1 == (unsigned)w2 ? 1u : 0u;
+                    }
+                }
+                sum = wave_sum_u32(sum);
+                const unsigned long long sm = __ballot(same != 0u);
+                if (lane == 0) {
+                    s_sum[0] = sum;
+                    s_same[0] = sm == ~0ull ? 1u : 0u;
+                    s_bad[0] = bad;
+                }
+            }
+            __syncthreads();
+            const unsigned long long before = s_sum[0];
+            const unsigned all_same = s_same[0], any_bad = s_bad[0];
+            __syncthreads();
+            t_wait += __builtin_amdgcn_s_memrealtime() - tw0;
+            bound = before < (unsigned long long)(n - 1) ? (unsigned)((unsigned long long)(n - 1) - before) : 0u;
+            final_now = r >= 2 && all_same != 0u;
+            if (any_bad != 0u) gave_up = true;
+        }
+        if (!gave_up && r >= max_rounds - 1 && !final_now) gave_up = true; // the history is used up
+        if (gave_up) break;
+        // -- the tail of the walk (bounds within one batch's worth of candidates: the walk ends in this batch or the next;
+        //    every batch behind it is tail too): until the batches before are at rest only an ESTIMATE is published -- the
+        //    expected count, a function of the bound, not marked exact -- and the one exact settle, plane after plane by one
+        //    wavefront, happens when the bound is final.  Batches of the tail become final one round after each other.
+        const bool tail = bound <= (unsigned)(XC_OG_WAVES * XC_OG_GROUP);
+        unsigned publish;
+        if (tail && !final_now) {
+            publish = bound - og_expected_from(bound, (double)(XC_OG_WAVES * XC_OG_GROUP));
+        } else {
+            // -- settle the batch from that bound (unless it is the bound it was last settled from: same result)
+            if (bound != bound_prev) {
+                const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+                ++settles;
+                if (tail) {
+                    og_tail_batch(S, n, steps, bound);
+                    ++inner;
+                } else {
+                    if (!have_prev) {
+                        og_guess_within(S, bound);
+                    } else if (threadIdx.x <= XC_OG_WAVES) { // the groups' bounds move with the batch's: the previous kept counts as the guess
+                        unsigned before = 0u;
+                        for (unsigned w = 0; w < threadIdx.x; ++w) before += s_prev_kept[w];
+                        S.enter[threadIdx.x] = before < bound ? bound - before : 0u;
+                    }
+                    __syncthreads();
+                    inner += og_batch(S, n, steps);
+                }
+                og_store_records(S, recs, (long long)b);
+                if (threadIdx.x < XC_OG_WAVES) s_prev_kept[threadIdx.x] = S.kept[threadIdx.x];
+                have_prev = !tail;
+                kept_total = bound - S.enter[XC_OG_WAVES];
+                bound_prev = bound;
+                __syncthreads();
+                t_settle += __builtin_amdgcn_s_memrealtime() - ts0;
+            }
+            publish = kept_total | 0x80000000u;
+        }
+        last_publish = publish;
+        if (final_now) break;
+        if (threadIdx.x == 0) og_st64(hist + (size_t)r * nb + b, epoch | publish);
+    }
+    // -- leaving: the rest of the history (the batches behind read it), and the end of the walk
+    if (gave_up && threadIdx.x == 0) {
+        og_st64(hdr + XC_OG_UNSETTLED, 1ull);
+        og_st64(hdr + XC_OG_ABORT, 1ull);
+    }
+    for (int q = r + (int)threadIdx.x; q < XC_OG_HIST_ROUNDS; q += blockDim.x) og_st64(hist + (size_t)q * nb + b, epoch | last_publish);
+    if (!gave_up && threadIdx.x == 0) {
+        const long long got_in = (long long)(n - 1) - (long long)bound_prev, got_out = got_in + kept_total;
+        if (got_in < steps && got_out >= steps) { // the walk ends in this batch
+            long long use = 0;
+            for (int g = 0; g < XC_OG_WAVES; ++g) use += S.used[g];
+            hdr[XC_OG_NEXT_CONSUMED] = (unsigned long long)(first + (long long)b * (XC_OG_WAVES * XC_OG_GROUP) + use);
+            hdr[XC_OG_NEXT_ROUNDS] = (unsigned long long)(r + 1);
+        } else if (b == nb - 1u && got_out < steps) {
+            hdr[XC_OG_NEXT_FLAG] = 1ull; // the candidate buffer is used up
+            hdr[XC_OG_NEXT_CONSUMED] = 0ull;
+        }
+    }
+    if (dbg != nullptr && threadIdx.x == 0) { // diagnostics (100 MHz ticks since the shuffle began)
+        const unsigned long long t0 = hdr[XC_OG_T0];
+        dbg[4 * b + 0] = t_begin - t0;
+        dbg[4 * b + 1] = __builtin_amdgcn_s_memrealtime() - t0;
+        dbg[4 * b + 2] = (t_wait << 32) | (t_settle & 0xFFFFFFFFull);
+        dbg[4 * b + 3] = ((unsigned long long)(r + 1) << 40) | ((unsigned long long)settles << 24) | (unsigned long long)inner;
     }
 }
 
@@ -528,6 +846,7 @@ __global__ __launch_bounds__(256) void og_arange_kernel(long long n, int32_t *a)
 }
 
 static int64_t og_align(int64_t b) { return (b + 255) / 256 * 256; }
+static int g_og_rounds = 0; // test knob: rounds the grid-wide walk may take (0: default; < 0: the one-workgroup walk only)
 
 } // namespace xc
 
@@ -566,8 +885,10 @@ int xc_order_dev_workspace_bytes(int64_t n, int64_t *bytes) {
     int rc = xc_order_dev_candidates(n, &count);
     if (rc) return rc;
     if (!bytes) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_workspace_bytes: NULL");
-    // header | raw[count + 2] | plane records[count / 64 + 256] | js[n] | head[n] | nxt[n] | root[n] | src[n]
-    *bytes = 256 + xc::og_align((count + 2) * 4) + xc::og_align((count / 64 + 256) * 16) + 5 * xc::og_align(n * 4 + 4);
+    // header | raw[count + 2] | plane records[count / 64 + 256] | js[n] | head[n] | nxt[n] | root[n] | src[n] | history of the
+    // grid-wide walk [64 rounds][batches]
+    *bytes = 256 + xc::og_align((count + 2) * 4) + xc::og_align((count / 64 + 256) * 16) + 5 * xc::og_align(n * 4 + 4) +
+             xc::og_align((int64_t)(XC_OG_HIST_ROUNDS + 4) * (count / (XC_OG_WAVES * XC_OG_GROUP) + 1) * 8); // + 4 words of diagnostics per batch
     return XC_OK;
 }
 
@@ -578,6 +899,10 @@ int xc_order_dev_begin(void *workspace, const uint64_t *state_inc, int consumed,
     if (!workspace || !state_inc || n < 0 || (n > 0 && !order) || consumed < 0 || consumed > 1)
         return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_begin: bad argument");
     hipStream_t st = xc::as_stream(stream);
+    int64_t bytes = 0;
+    int rc = xc_order_dev_workspace_bytes(n, &bytes);
+    if (rc) return rc;
+    XC_HIP_TRY(hipMemsetAsync(workspace, 0, (size_t)bytes, st)); // (the grid-wide walk's history must not carry a tag yet)
     hipLaunchKernelGGL(xc::og_init_kernel, dim3(1), dim3(64), 0, st, static_cast<unsigned long long *>(workspace), state_inc[0],
                        state_inc[1], state_inc[2], state_inc[3], (unsigned long long)consumed);
     if (n > 0) hipLaunchKernelGGL(xc::og_arange_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long long)n, order);
@@ -611,11 +936,20 @@ int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, in
     unsigned *js = reinterpret_cast<unsigned *>(q);
     int *head = reinterpret_cast<int *>(q + seg), *nxt = reinterpret_cast<int *>(q + 2 * seg);
     int *root = reinterpret_cast<int *>(q + 3 * seg), *src = reinterpret_cast<int *>(q + 4 * seg);
+    unsigned long long *hist = reinterpret_cast<unsigned long long *>(q + 5 * seg);
+    const unsigned batches = (unsigned)((count - 2) / (XC_OG_WAVES * XC_OG_GROUP)); // whole batches behind the first candidate (raw index 0 or 1)
+    int max_rounds = XC_OG_HIST_ROUNDS;
+    if (xc::g_og_rounds > 0 && xc::g_og_rounds < XC_OG_HIST_ROUNDS) max_rounds = xc::g_og_rounds;
     const long long steps = n - 1;
     const unsigned gb = (unsigned)((steps + 255) / 256);
     XC_HIP_TRY(hipMemsetAsync(head, 0xff, (size_t)n * 4, st));
     hipLaunchKernelGGL(xc::og_raw_kernel, dim3((unsigned)((count / 16 + 256) / 256)), dim3(256), 0, st, hdr, raw, (long long)count);
-    hipLaunchKernelGGL(xc::og_walk_kernel, dim3(1), dim3(XC_OG_WAVES * 64), 0, st, hdr, raw, (long long)count, (long long)n, recs);
+    const bool grid = batches >= 2 && xc::g_og_rounds >= 0;
+    if (grid)
+        hipLaunchKernelGGL(xc::og_walk_grid_kernel, dim3(batches), dim3(XC_OG_WAVES * 64), 0, st, hdr, raw, (long long)n, recs, hist, max_rounds,
+                           hist + (size_t)XC_OG_HIST_ROUNDS * batches);
+    hipLaunchKernelGGL(xc::og_walk_kernel, dim3(1), dim3(XC_OG_WAVES * 64), 0, st, hdr, raw, (long long)count, (long long)n, recs,
+                       grid ? 1 : 0, batches);
     hipLaunchKernelGGL(xc::og_compact_kernel, dim3((unsigned)((count / 64 + 4) / 4)), dim3(256), 0, st, hdr, raw, recs, (long long)n, js);
     hipLaunchKernelGGL(xc::og_lists_kernel, dim3(gb), dim3(256), 0, st, steps, js, head, nxt);
     hipLaunchKernelGGL(xc::og_links_kernel, dim3(gb), dim3(256), 0, st, (long long)n, js, head, nxt, root, src);
@@ -623,6 +957,32 @@ int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, in
     hipLaunchKernelGGL(xc::og_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long long)n, root, src, head, nxt,
                        order_in, order_out, hdr);
     XC_CHECK_LAUNCH("order generator kernels");
+    return XC_OK;
+}
+
+// Diagnostics of the last grid-wide walk: per batch {start, end (100 MHz ticks since the shuffle began), ticks waiting <<
+// 32 | ticks settling, rounds << 40 | settles << 24 | inner rounds}; out must hold 4 * batches words.  Blocks on the stream.
+int xc_order_dev_walk_trace(void *workspace, int64_t n, int64_t *out, int64_t *batches_out, void *stream) {
+    if (!workspace || !batches_out || n < 2) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_walk_trace: bad argument");
+    int64_t count = 0;
+    int rc = xc_order_dev_candidates(n, &count);
+    if (rc) return rc;
+    const int64_t batches = count / (XC_OG_WAVES * XC_OG_GROUP);
+    *batches_out = batches;
+    if (!out) return XC_OK;
+    const char *q = static_cast<const char *>(workspace) + 256 + xc::og_align((count + 2) * 4) + xc::og_align((count / 64 + 256) * 16) +
+                    5 * xc::og_align(n * 4 + 4);
+    const unsigned long long *dbg = reinterpret_cast<const unsigned long long *>(q) + (size_t)XC_OG_HIST_ROUNDS * batches;
+    hipStream_t st = xc::as_stream(stream);
+    XC_HIP_TRY(hipMemcpyAsync(out, dbg, (size_t)batches * 32, hipMemcpyDeviceToHost, st));
+    XC_HIP_TRY(hipStreamSynchronize(st));
+    return XC_OK;
+}
+
+// Test knob: rounds the grid-wide walk may take (0 = default, 64).  With 1 or 2 it gives up on a large shuffle and the
+// one-workgroup walk behind it redoes the shuffle: same result.  Negative: the one-workgroup walk only.
+int xc_order_dev_set_rounds(int rounds) {
+    xc::g_og_rounds = rounds;
     return XC_OK;
 }
 
@@ -641,6 +1001,7 @@ int xc_order_dev_status(void *workspace, int64_t *out3_host, void *stream) {
     out3_host[4] = (int64_t)tmp[XC_OG_TICKS];
     out3_host[5] = (int64_t)tmp[XC_OG_ROUNDS];
     out3_host[6] = (int64_t)tmp[XC_OG_BATCHES];
+    out3_host[7] = (int64_t)tmp[XC_OG_FALLBACK];
     return XC_OK;
 }
 

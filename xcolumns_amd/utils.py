@@ -281,6 +281,30 @@ def pcg64_advance(state: int, inc: int, steps: int) -> int:
     return (acc_mult * state + acc_plus) & _MASK128
 
 
+# Generators that work on a side stream.  Their rejection walk (one workgroup per batch, each waiting for lower-numbered
+# workgroups) and the ordered sweep (csrc/xc_bca_ord.hip: a grid barrier over one workgroup per CU) must not be
+# dispatched into each other: a walk that is only partly resident when the ordered sweep takes the remaining CUs would
+# stall it until the walk's waits time out.  The engine fences them apart (`order_generators_fence`).
+_LIVE_SIDE_GENERATORS = None
+
+
+def order_generators_fence(before: bool) -> None:
+    """before=True: the current stream waits for everything the live generators have enqueued on their side streams;
+    before=False: their side streams wait for everything enqueued on the current stream so far."""
+    import torch
+    if not _LIVE_SIDE_GENERATORS:
+        return
+    cur = torch.cuda.current_stream()
+    for g in list(_LIVE_SIDE_GENERATORS):
+        side = getattr(g, "side", None)
+        if side is None:
+            continue
+        if before:
+            cur.wait_stream(side)
+        else:
+            side.wait_stream(cur)
+
+
 class DeviceNumpyOrders:
     """``rng.shuffle(order)`` of a ``np.random.default_rng`` generator, cumulatively, ON the GPU
     (csrc/xc_order_dev.hip): :meth:`next` returns the int32 order tensor of the next sweep -- the permutation numpy
@@ -293,7 +317,7 @@ class DeviceNumpyOrders:
     _ok = None
     DEPTH = 4     # order buffers in rotation
 
-    def __init__(self, rng: np.random.Generator, n: int, device, ahead: int = 2):
+    def __init__(self, rng: np.random.Generator, n: int, device, ahead: int = 2, limit=None):
         import ctypes
 
         import torch
@@ -301,6 +325,7 @@ class DeviceNumpyOrders:
         from . import _device as D
         from . import _lib
         self.rng, self.n, self.dev = rng, int(n), device
+        self.limit = (1 << 62) if limit is None else int(limit)   # orders the consumer can ask for: none beyond are made
         self.ahead = int(max(0, min(ahead, self.DEPTH - 2)))
         st = rng.bit_generator.state
         if st["bit_generator"] != "PCG64":
@@ -315,6 +340,11 @@ class DeviceNumpyOrders:
         self.bufs = [torch.empty(max(1, self.n), dtype=torch.int32, device=device) for _ in range(self.DEPTH)]
         self.side = torch.cuda.Stream(device=device) if self.ahead > 0 else None
         if self.side is not None:
+            global _LIVE_SIDE_GENERATORS
+            if _LIVE_SIDE_GENERATORS is None:
+                import weakref
+                _LIVE_SIDE_GENERATORS = weakref.WeakSet()
+            _LIVE_SIDE_GENERATORS.add(self)
             # the side stream works on these tensors: the allocator must not hand their memory to anybody else before
             # that work has finished, even if this object is dropped without finish()
             self.ws.record_stream(self.side)
@@ -329,7 +359,7 @@ class DeviceNumpyOrders:
         self.handed = 0             # orders handed to the consumer
         self._done = {}             # shuffle number -> event on the side stream
         self._free = {}             # order number -> event on the consumer's stream recorded when the NEXT order was handed out
-        for _ in range(self.ahead):
+        for _ in range(min(self.ahead, self.limit)):
             self._generate()
 
     def __del__(self):
@@ -369,7 +399,7 @@ class DeviceNumpyOrders:
             ev = torch.cuda.Event()
             ev.record(cur)
             self._free[k] = ev
-        while self.generated < k + self.ahead:
+        while self.generated < max(k, min(k + self.ahead, self.limit)):
             self._generate()
         if self.side is not None:
             cur.wait_event(self._done.pop(k))
@@ -386,7 +416,8 @@ class DeviceNumpyOrders:
         out = (ctypes.c_int64 * 8)()
         with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
             _lib.call("xc_order_dev_status", D.ptr(self.ws), out, D.stream())
-        self.last_walk = {"cycles": int(out[3]), "us": int(out[4]) / 100.0, "rounds": int(out[5]), "batches": int(out[6])}
+        self.last_walk = {"cycles": int(out[3]), "us": int(out[4]) / 100.0, "rounds": int(out[5]), "batches": int(out[6]),
+                          "fallbacks": int(out[7])}
         return int(out[0]), int(out[1]), int(out[2])
 
     def finish(self, sync_rng: bool = False) -> None:
