@@ -609,12 +609,12 @@ int xc_order_dev_begin(void *workspace, const uint64_t *state_inc, int consumed,
 /* order_out <- one Generator.shuffle of order_in (int32[n] each, device, distinct); asynchronous on `stream`. */
 int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, int32_t *order_out, void *stream);
 /* out8_host = {failure flag (0: every shuffle so far is numpy's), 32-bit draws consumed, shuffles, shader cycles and
- * 100 MHz ticks of the last rejection walk, its rounds and batches, walks redone by the one-workgroup fallback};
+ * 100 MHz ticks of the last rejection walk, its rounds and batches, walks redone by the one-wavefront fallback};
  * blocks on `stream`. */
 int xc_order_dev_status(void *workspace, int64_t *out8_host, void *stream);
 /* Test knob: rounds the grid-wide rejection walk may take (0 = default, 64; 18-25 are needed).  With too few it gives up and
- * the one-workgroup walk behind it redoes the shuffle: the same permutation, ~2 ms per million rows.  Negative: the
- * one-workgroup walk only. */
+ * the one-wavefront walk behind it redoes the shuffle: the same permutation, ~8 ms per million rows.  Negative: the
+ * one-wavefront walk only. */
 int xc_order_dev_set_rounds(int rounds);
 /* Diagnostics of the last rejection walk, per batch of 8192 candidates: {start, end (100 MHz ticks since the shuffle
  * began), ticks waiting << 32 | ticks settling, rounds << 40 | settles << 24 | inner rounds}; out = NULL: only the number

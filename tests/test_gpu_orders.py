@@ -23,7 +23,7 @@ def test_device_orders_are_numpys(n):
             mine = gen.next().cpu().numpy()
             assert np.array_equal(ref, mine), (n, seed, s, int((ref != mine).sum()))
         gen.finish(sync_rng=True)
-        # the grid-wide rounds settled every walk themselves (no walk was left to the one-workgroup fallback)
+        # the grid-wide rounds settled every walk themselves (no walk was left to the one-wavefront fallback)
         assert gen.last_walk["fallbacks"] == 0 and 1 <= gen.last_walk["rounds"] <= 40, gen.last_walk
         # the Python generator is where numpy's own shuffles would have left it
         assert a.integers(0, 1 << 62, size=5).tolist() == b.integers(0, 1 << 62, size=5).tolist()
@@ -31,7 +31,7 @@ def test_device_orders_are_numpys(n):
 
 @pytest.mark.parametrize("rounds", [1, 3])
 def test_device_orders_fall_back_to_the_one_workgroup_walk(rounds):
-    """Given too few rounds the grid-wide walk gives up: the one-workgroup walk behind it redoes the shuffle -- the
+    """Given too few rounds the grid-wide walk gives up: the one-wavefront walk behind it redoes the shuffle -- the
     same permutations and generator position (the safety net of csrc/xc_order_dev.hip, never taken by default)."""
     from xcolumns_amd import _device as D
     from xcolumns_amd import _lib

@@ -44,13 +44,13 @@ typedef unsigned __int128 u128;
 #define XC_OG_FIRST 11     /* raw index of the last walk's first candidate (0 or 1) */
 #define XC_OG_ROUNDS 12    /* rounds of the last walk (diagnostics) */
 #define XC_OG_T0 13        /* 100 MHz tick at which the last shuffle began (raw kernel) */
-#define XC_OG_FALLBACK 14  /* walks the grid-wide kernel did not settle and the one-workgroup walk redid */
+#define XC_OG_FALLBACK 14  /* walks the grid-wide kernel did not settle and the one-wavefront walk redid */
 #define XC_OG_EPOCH 15     /* shuffle number the grid-wide walk tags its publications with */
 // staged by the grid-wide walk, committed behind it (its late workgroups still read the words above)
 #define XC_OG_NEXT_CONSUMED 16
 #define XC_OG_NEXT_FLAG 17
 #define XC_OG_NEXT_ROUNDS 18
-#define XC_OG_UNSETTLED 19 /* != 0: the grid-wide walk gave up (rounds exhausted / a wait timed out): the one-workgroup walk redoes it */
+#define XC_OG_UNSETTLED 19 /* != 0: the grid-wide walk gave up (rounds exhausted / a wait timed out): the one-wavefront walk redoes it */
 #define XC_OG_ABORT 20
 #define XC_OG_WORDS 24
 
@@ -462,12 +462,15 @@ __device__ __forceinline__ void og_tail_batch(OgShared &S, long long n, long lon
     __syncthreads();
 }
 
-// The one-workgroup walk: batch after batch.  Behind the grid-wide walk below it is the safety net: it commits what that
-// one staged and returns, unless the grid-wide walk gave up -- then it walks the shuffle itself.
-__global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long long *hdr, const unsigned *raw, long long count, long long n,
-                                                                    OgRec *recs, int behind_grid, unsigned grid_batches) {
+// Behind the grid-wide walk (below), ONE wavefront: it commits what that walk staged and returns -- or, if that walk gave up
+// (never observed), walks the shuffle itself, plane after plane from the candidates in memory (og_one_plane: exact whatever
+// the mask does): ~8 ms per million rows, the safety net that keeps the result exact.  One wavefront without LDS so that
+// the launch finds a place at once on a GPU the sweeps keep full (as a 1024-thread workgroup it waited up to 0.65 ms).
+__global__ __launch_bounds__(64) void og_walk_kernel(unsigned long long *hdr, const unsigned *raw, long long count, long long n,
+                                                     OgRec *recs, int behind_grid, unsigned grid_batches) {
+    const int lane = threadIdx.x;
     if (behind_grid && hdr[XC_OG_UNSETTLED] == 0ull) {
-        if (threadIdx.x == 0) { // commit the grid-wide walk's result (its workgroups have all left)
+        if (lane == 0) { // commit the grid-wide walk's result (its workgroups have all left)
             const unsigned long long first = hdr[XC_OG_CONSUMED] & 1ull;
             if (hdr[XC_OG_NEXT_FLAG] != 0ull) hdr[XC_OG_FLAG] = hdr[XC_OG_NEXT_FLAG];
             hdr[XC_OG_BATCHES] = (unsigned long long)grid_batches;
@@ -480,60 +483,50 @@ __global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long
         }
         return;
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ OgShared S;
     const long long first = (long long)__builtin_amdgcn_readfirstlane((int)(hdr[XC_OG_CONSUMED] & 1ull)); // odd: the low half of that output is spent
     const long long steps = n - 1;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned i_batch = (unsigned)(n - 1); // bound when the batch begins (exact)
-    long long consumed = first, batch = 0;
+    unsigned i = (unsigned)(n - 1);
+    long long got = 0, plane = 0, consumed = first;
     bool fail = false;
-    long long rounds = 0;
-    unsigned nxt[XC_OG_PLANES];
-    {
-        const long long b0 = first + (long long)wv * XC_OG_GROUP;
-#pragma unroll
-        for (int p = 0; p < XC_OG_PLANES; ++p) nxt[p] = b0 + p * 64 + lane < count ? raw[b0 + p * 64 + lane] : 0u;
-    }
-    while ((long long)(n - 1) - (long long)i_batch < steps) { // steps done so far = n - 1 - i_batch
-        const long long base = first + batch * (XC_OG_WAVES * XC_OG_GROUP);
-        if (base + XC_OG_WAVES * XC_OG_GROUP > count) { // the candidate buffer is used up (sized for the expectation + 8 sigma)
+    while (got < steps) {
+        const long long base = first + plane * 64;
+        if (base + 64 > count) { // the candidate buffer is used up (sized for the expectation + 8 sigma)
             fail = true;
             break;
         }
-#pragma unroll
-        for (int p = 0; p < XC_OG_PLANES; ++p) S.raw[wv * XC_OG_GROUP + p * 64 + lane] = nxt[p];
-        {   // the next batch's candidates, in flight during the rounds
-            const long long b1 = base + XC_OG_WAVES * XC_OG_GROUP + (long long)wv * XC_OG_GROUP;
-#pragma unroll
-            for (int p = 0; p < XC_OG_PLANES; ++p) nxt[p] = b1 + p * 64 + lane < count ? raw[b1 + p * 64 + lane] : 0u;
+        const unsigned i_begin = i;
+        int used = 0;
+        unsigned follows = 0u;
+        const unsigned long long a = og_one_plane(raw + base, lane, steps, got, i, used, follows);
+        if (lane == 0) {
+            OgRec rc;
+            rc.bound = i_begin;
+            rc.one_by_one = follows;
+            rc.kept = a;
+            recs[plane] = rc;
         }
-        if (i_batch <= (unsigned)(XC_OG_WAVES * XC_OG_GROUP)) { // the tail: one wavefront, plane after plane
-            og_tail_batch(S, n, steps, i_batch);
-            ++rounds;
-        } else {
-            og_guess_within(S, i_batch);
-            __syncthreads();
-            rounds += og_batch(S, n, steps);
-        }
-        // the batch's records; candidates consumed (only the group in which the walk ends consumes fewer than 512)
-        og_store_records(S, recs, batch);
-        long long use = 0;
-        for (int g = 0; g < XC_OG_WAVES; ++g) use += S.used[g];
-        consumed = base + use;
-        i_batch = S.enter[XC_OG_WAVES];
-        ++batch;
-        __syncthreads();
+        consumed = base + used;
+        ++plane;
     }
-    if (threadIdx.x == 0) {
+    // the compaction works on whole batches of 128 planes: the rest of the last one holds nothing
+    const long long batches = (plane + XC_OG_WAVES * XC_OG_PLANES - 1) / (XC_OG_WAVES * XC_OG_PLANES);
+    for (long long q = plane + lane; q < batches * (XC_OG_WAVES * XC_OG_PLANES); q += 64) {
+        OgRec z;
+        z.bound = 0u;
+        z.one_by_one = 0u;
+        z.kept = 0ull;
+        recs[q] = z;
+    }
+    if (lane == 0) {
         if (fail) hdr[XC_OG_FLAG] = 1ull;
-        hdr[XC_OG_BATCHES] = (unsigned long long)batch;
+        hdr[XC_OG_BATCHES] = (unsigned long long)batches;
         hdr[XC_OG_FIRST] = (unsigned long long)first;
         hdr[XC_OG_CONSUMED] = (hdr[XC_OG_CONSUMED] & ~1ull) + (unsigned long long)consumed;
         hdr[XC_OG_SHUFFLES] += 1ull;
         hdr[XC_OG_CYCLES] = __builtin_amdgcn_s_memtime() - c0;
         hdr[XC_OG_TICKS] = __builtin_amdgcn_s_memrealtime() - r0;
-        hdr[XC_OG_ROUNDS] = (unsigned long long)rounds;
+        hdr[XC_OG_ROUNDS] = (unsigned long long)plane;
         if (behind_grid) hdr[XC_OG_FALLBACK] += 1ull;
     }
 }
@@ -553,7 +546,7 @@ __global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_kernel(unsigned long
 // co-residency and cannot deadlock against other kernels.  Workgroup b is FINAL in round r when every h < b published the
 // same count in rounds r - 1 and r - 2: then all bounds below b are where they were a round ago, so are their counts, and by
 // induction they never move again; it settles from its bound, fills the rest of its history with that count and leaves.
-// The workgroup in which the walk ends stages the generator's new position; og_walk_kernel (one workgroup, behind this
+// The workgroup in which the walk ends stages the generator's new position; og_walk_kernel (one wavefront, behind this
 // launch) commits it -- or, if this kernel gave up (rounds exhausted, a wait that timed out: never observed), walks the
 // shuffle itself: the result is exact whatever happens here.
 #define XC_OG_HIST_ROUNDS 64
@@ -846,7 +839,7 @@ __global__ __launch_bounds__(256) void og_arange_kernel(long long n, int32_t *a)
 }
 
 static int64_t og_align(int64_t b) { return (b + 255) / 256 * 256; }
-static int g_og_rounds = 0; // test knob: rounds the grid-wide walk may take (0: default; < 0: the one-workgroup walk only)
+static int g_og_rounds = 0; // test knob: rounds the grid-wide walk may take (0: default; < 0: the one-wavefront walk only)
 
 } // namespace xc
 
@@ -948,8 +941,7 @@ int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, in
     if (grid)
         hipLaunchKernelGGL(xc::og_walk_grid_kernel, dim3(batches), dim3(XC_OG_WAVES * 64), 0, st, hdr, raw, (long long)n, recs, hist, max_rounds,
                            hist + (size_t)XC_OG_HIST_ROUNDS * batches);
-    hipLaunchKernelGGL(xc::og_walk_kernel, dim3(1), dim3(XC_OG_WAVES * 64), 0, st, hdr, raw, (long long)count, (long long)n, recs,
-                       grid ? 1 : 0, batches);
+    hipLaunchKernelGGL(xc::og_walk_kernel, dim3(1), dim3(64), 0, st, hdr, raw, (long long)count, (long long)n, recs, grid ? 1 : 0, batches);
     hipLaunchKernelGGL(xc::og_compact_kernel, dim3((unsigned)((count / 64 + 4) / 4)), dim3(256), 0, st, hdr, raw, recs, (long long)n, js);
     hipLaunchKernelGGL(xc::og_lists_kernel, dim3(gb), dim3(256), 0, st, steps, js, head, nxt);
     hipLaunchKernelGGL(xc::og_links_kernel, dim3(gb), dim3(256), 0, st, (long long)n, js, head, nxt, root, src);
@@ -980,7 +972,7 @@ int xc_order_dev_walk_trace(void *workspace, int64_t n, int64_t *out, int64_t *b
 }
 
 // Test knob: rounds the grid-wide walk may take (0 = default, 64).  With 1 or 2 it gives up on a large shuffle and the
-// one-workgroup walk behind it redoes the shuffle: same result.  Negative: the one-workgroup walk only.
+// one-wavefront walk behind it redoes the shuffle: same result.  Negative: the one-wavefront walk only.
 int xc_order_dev_set_rounds(int rounds) {
     xc::g_og_rounds = rounds;
     return XC_OK;
