@@ -169,14 +169,15 @@ class WavePolicy:
                 # About ONE predicted row per label (150 K rows x 670 K labels): 35 / 19 / 55 wavefronts still ended a
                 # sweep at 8.0e-6 and 1.02e-5 in two of five runs, and nothing heals afterwards.  The reference itself
                 # moves by 1.2-3.8e-5 (standard deviation) there when only its visiting order changes, so its trajectory
-                # cannot be tracked to 1e-5 by anything but its own sequence: these shapes run the sequential sweep
-                # (exact; 0.25 s per sweep at C3) unless the caller asks for bca_parity="final" or a width.
+                # cannot be tracked to 1e-5 by anything but its own sequence: these shapes run the EXACT sweep -- since
+                # round 3 the ordered parallel sweep (csrc/xc_bca_ord.hip: 0.5-1.7 ms per sweep at C3; one wavefront took
+                # 0.25 s) -- unless the caller asks for bca_parity="final" or a width.  (fixed = 1 means "exact" below too.)
                 self.fixed = 1
             if per_label < 8.0 and float(m) < 30000.0 and self.parity == "per_sweep" and not self.fixed:
                 # few predicted rows per label on a SMALL label space: one decision that falls the other way is the
                 # whole bar (1 / m per label), and 17-35 wavefronts still measured 1.5e-5 on 37 K x 20 K, k = 2
                 # (3.7 rows per label; the fuzz of round 2, seed 1065), 11-27 wavefronts 1.3e-5 on 22 K x 10.5 K, k = 2
-                # (4.1; seed 3059) -- a sequential sweep of such a matrix takes 40-60 ms
+                # (4.1; seed 3059): the exact sweep
                 self.fixed = 1
             if 2.0 * max(1, int(k)) > float(row_nnz) and self.parity == "per_sweep" and not self.fixed:
                 # a budget of more than half of a row's candidates (35 K x 14 K, 12 entries per row, k = 7: the fuzz of
@@ -209,8 +210,8 @@ class WavePolicy:
                 # wavefronts 1.9-3.6e-4 after sweep 1, 2.9-4.3e-6 after sweep 2, <= 3e-7 from sweep 3 on (three visiting
                 # orders, profiles/r02_c3_width.txt); 1 M x 500 K: 3.2e-5, then 3.8e-7.  "final" promises the last sweep.
                 self.first_factor = 1.0
-            # ... and when that leaves fewer than 64 wavefronts the first sweep runs as the reference's sequential
-            # sweep: on 100 K x 30 K Zipf ONE tail label that is predicted by a different row is 1-2e-5 of utility,
+            # ... and when that leaves fewer than 64 wavefronts the first sweep runs as the reference's own sequence
+            # (the exact sweep: 4.9 ms at 100 K x 30 K with the ordered parallel sweep, 0.26 s with one wavefront): on 100 K x 30 K Zipf ONE tail label that is predicted by a different row is 1-2e-5 of utility,
             # and 22 .. 250 wavefronts all measure 0.5-2e-5 in sweep 1 (six runs each, profiles/r02_c2_zipf_width.txt)
             # -- anything but one row at a time is a coin toss against the bar there.
             if (skewed and self.parity == "per_sweep" and not self.fixed
@@ -608,7 +609,15 @@ class BcaCsrEngine:
             wg, win = ctypes.c_int(0), ctypes.c_int(0)
             _lib.call("xc_bca_ord_window", ctypes.byref(wg), ctypes.byref(win))
             env_wg = os.environ.get("XCOLUMNS_BCA_ORD_WORKGROUPS")
-            self._ord_wg = max(1, min(int(env_wg), wg.value)) if env_wg else wg.value
+            # Two CUs per XCD stay free (workgroups go to the XCDs round robin, one per CU): the kernel's grid barrier needs
+            # all its workgroups resident, and the visiting-order generator's rejection walk (csrc/xc_order_dev.hip: a
+            # workgroup per batch, each waiting for lower-numbered ones) must always find a CU for its lowest unfinished
+            # workgroup -- with every CU taken by a workgroup that spins at the barrier, a walk that is only partly resident
+            # and this kernel would wait for each other until their spin limits.  With CUs to spare the two overlap freely
+            # (fencing them apart with events cost 0.3 ms per sweep at 150 K rows).
+            spare = int(os.environ.get("XCOLUMNS_BCA_ORD_SPARE_CUS", "16"))
+            dflt = wg.value - spare if wg.value >= 8 * spare else wg.value
+            self._ord_wg = max(1, min(int(env_wg), wg.value)) if env_wg else dflt
             self._ord_waves = max(1, win.value // max(1, wg.value))            # wavefronts per workgroup
             self._ord_max_rpw = 4 if self._ord_waves >= 16 else 8              # rows x candidates per lane a wavefront's registers hold
             # rows per wavefront: rows x candidates per lane <= 4 stay in registers for a window's iterations; small
@@ -667,15 +676,12 @@ class BcaCsrEngine:
             for dd in self._ord_dirs.values():
                 dd["ws"].zero_()
             self._ord_epoch = 1 << 20
-        from .utils import order_generators_fence
-        order_generators_fence(True)     # no visiting-order walk is dispatched into the grid barrier of this kernel
         _lib.call("xc_bca_ord_sweep", D.ptr(d["ws"]), int(n_order), D.ptr(order), self.n_total, D.ptr(c.indptr),
                   D.ptr(c.indices), D.ptr(c.data), c.code, int(c.max_row_nnz), D.ptr(self.pred_idx), D.ptr(self.pred_eta),
                   D.ptr(self.sel), D.ptr(self.orphans), self.k, c.m, D.ptr(self.tpfp), D.ptr(self.s_entry), D.ptr(d["lab_dir"]),
                   d["total_cap"], D.ptr(d["hot_labels"]), d["n_hot"], self._ord_wg, self._ord_rpw, ctypes.byref(self.gain_metric),
                   int(self.maximize), int(self.skip_tn), ctypes.c_uint32(self._ord_epoch), D.ptr(self.changed), status,
                   D.stream())
-        order_generators_fence(False)
         self._ord_epoch += 1 << 20
         done, err = int(status[0]), int(status[1])
         self.ordered_stats = {"iterations": int(status[2]), "windows": int(status[3]), "done": done, "error": err,

@@ -281,30 +281,6 @@ def pcg64_advance(state: int, inc: int, steps: int) -> int:
     return (acc_mult * state + acc_plus) & _MASK128
 
 
-# Generators that work on a side stream.  Their rejection walk (one workgroup per batch, each waiting for lower-numbered
-# workgroups) and the ordered sweep (csrc/xc_bca_ord.hip: a grid barrier over one workgroup per CU) must not be
-# dispatched into each other: a walk that is only partly resident when the ordered sweep takes the remaining CUs would
-# stall it until the walk's waits time out.  The engine fences them apart (`order_generators_fence`).
-_LIVE_SIDE_GENERATORS = None
-
-
-def order_generators_fence(before: bool) -> None:
-    """before=True: the current stream waits for everything the live generators have enqueued on their side streams;
-    before=False: their side streams wait for everything enqueued on the current stream so far."""
-    import torch
-    if not _LIVE_SIDE_GENERATORS:
-        return
-    cur = torch.cuda.current_stream()
-    for g in list(_LIVE_SIDE_GENERATORS):
-        side = getattr(g, "side", None)
-        if side is None:
-            continue
-        if before:
-            cur.wait_stream(side)
-        else:
-            side.wait_stream(cur)
-
-
 class DeviceNumpyOrders:
     """``rng.shuffle(order)`` of a ``np.random.default_rng`` generator, cumulatively, ON the GPU
     (csrc/xc_order_dev.hip): :meth:`next` returns the int32 order tensor of the next sweep -- the permutation numpy
@@ -340,11 +316,6 @@ class DeviceNumpyOrders:
         self.bufs = [torch.empty(max(1, self.n), dtype=torch.int32, device=device) for _ in range(self.DEPTH)]
         self.side = torch.cuda.Stream(device=device) if self.ahead > 0 else None
         if self.side is not None:
-            global _LIVE_SIDE_GENERATORS
-            if _LIVE_SIDE_GENERATORS is None:
-                import weakref
-                _LIVE_SIDE_GENERATORS = weakref.WeakSet()
-            _LIVE_SIDE_GENERATORS.add(self)
             # the side stream works on these tensors: the allocator must not hand their memory to anybody else before
             # that work has finished, even if this object is dropped without finish()
             self.ws.record_stream(self.side)
