@@ -79,6 +79,24 @@ def test_sharded_bca_four_ranks_default_schedule():
     assert all(b > a - 1e-6 for a, b in zip(got, got[1:]))
 
 
+def test_sharded_exact_sweeps_exchange_inside_the_sweep():
+    """A shape whose default sweeps are the EXACT ones (1.7 predicted rows per label: WavePolicy fixes the width at 1) on two
+    row shards: BcaCsrEngine.sweep_segments walks each rank's order in parts -- the ordered parallel sweep per part -- and the
+    ranks exchange what their rows changed (float64 records) between two parts, as the schedule asks; both ranks report
+    the same trace, the last utility is the utility of the assembled prediction (asserted in the script), and the trace
+    closes in on the sequential oracle's.  (Two processes share the GPU here: each ordered sweep takes 96 CUs so that both
+    grids are resident together.)"""
+    out = _run("bca_sharded_rehearsal.py", {"XC_BCA_REHEARSAL_SHAPE": "40000,120000,4", "XC_BCA_REHEARSAL_ORACLE": "1",
+                                            "XCOLUMNS_BCA_ORD_WORKGROUPS": "96"})
+    got, ref = _traces(out)
+    d = [abs(a - b) for a, b in zip(got, ref)]
+    ex = [int(x) for x in re.search(r"^exchanges \[(.*?)\]", out, re.M).group(1).split(",")]
+    print("two shards, exact sweeps, exchanges", ex, "diff per sweep", d)
+    assert len(got) == len(ref) == 4 and ex[0] >= 8 and min(ex) >= 2
+    # measured: exchanges [16, 16, 14, 5], 6.7e-4, 1.6e-4, 3.2e-5, 1.2e-5 (Jacobi across the shards: section 7 of DESIGN.md)
+    assert d[0] < 2e-3 and d[-1] < d[0] / 10 and all(b > a - 1e-6 for a, b in zip(got, got[1:]))
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()     # counting devices does not initialise the GPU in this process
