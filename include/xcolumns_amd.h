@@ -176,6 +176,15 @@ int xc_confusion_csr_pred_side(int64_t n, int64_t m, const int32_t *t_indptr,
                                const void *p_data, int dtype, double *tp, double *fp, double *fn,
                                int32_t *flag, void *stream);
 
+/* The prediction-side form for a 0/1 prediction without global atomics: val[q] <- y_true's value at the label of predicted
+ * entry q (0 where the row does not store it), float32.  Then xc_scatter_sum_f32(nnz(y_pred), p_indices, val, m, pair = 1)
+ * gives {tp, fp} per label (tp = sum val, fp = sum (1 - val) in float32: (T)(p (1 - t)) with p = 1,
+ * numba_csr_functions.py:197-206) and fn = column sums of y_true - tp.  *flag |= 1: a y_pred row is not strictly
+ * ascending, |= 2: a stored y_pred value is not 1 (take xc_confusion_csr_pred_side / xc_confusion_csr then). */
+int xc_confusion_csr_match(int64_t n, const int32_t *t_indptr, const int32_t *t_indices, const float *t_data,
+                           const int32_t *p_indptr, const int32_t *p_indices, const float *p_data, float *val,
+                           int32_t *flag, void *stream);
+
 /* dense branch (confusion_matrix.py:160-166, :187-202): products in `dtype`,
  * column sums in float64.  y_true, y_pred: n x m contiguous. */
 int xc_confusion_dense(int64_t n, int64_t m, const void *y_true, const void *y_pred,

@@ -248,14 +248,22 @@ def test_confusion_prediction_side_vs_oracle(oref, dtype, monkeypatch):
     T = Y.copy()
     T.data = (rng.random(T.nnz) < 0.4).astype(dtype) * T.data     # y_true: some entries kept, some explicit zeros
     Td, Yd = DeviceCSR.from_scipy(T), DeviceCSR.from_scipy(Y)
-    Pd = predict_top_k(Yd, k, keep_scores=True)
-    P = Pd.to_scipy()
-    exp = np.stack(oref.calculate_confusion_matrix(T, P, skip_tn=True)[:3])
-    for call in range(2):                               # second call: column sums and row check come from the cache
-        C = calculate_confusion_matrix(Td, Pd, skip_tn=True, dtype=torch.float64)
-        got = np.stack([C.tp.cpu().numpy(), C.fp.cpu().numpy(), C.fn.cpu().numpy()])
-        assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), call
-        assert "_colsum64" in Td.__dict__ and Td.rows_ascending()
+    # a 0/1 prediction (float32: matched, then summed by a counting sort -- no global atomics: xc_confusion_csr_match +
+    # xc_scatter_sum_f32) and one that keeps its scores (atomics for the predicted entries)
+    for keep_scores in (False, True):
+        Pd = predict_top_k(Yd, k, keep_scores=keep_scores)
+        P = Pd.to_scipy()
+        exp = np.stack(oref.calculate_confusion_matrix(T, P, skip_tn=True)[:3])
+        for call in range(2):                           # second call: column sums and row check come from the cache
+            C = calculate_confusion_matrix(Td, Pd, skip_tn=True, dtype=torch.float64)
+            got = np.stack([C.tp.cpu().numpy(), C.fp.cpu().numpy(), C.fn.cpu().numpy()])
+            assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), (keep_scores, call)
+            assert "_colsum64" in Td.__dict__ and Td.rows_ascending()
+        if not keep_scores:
+            monkeypatch.setenv("XCOLUMNS_CONFUSION_SCATTER", "0")   # the same through the atomic form
+            C = calculate_confusion_matrix(Td, Pd, skip_tn=True, dtype=torch.float64)
+            assert np.allclose(np.stack([C.tp.cpu().numpy(), C.fp.cpu().numpy(), C.fn.cpu().numpy()]), got, rtol=1e-12, atol=1e-12)
+            monkeypatch.delenv("XCOLUMNS_CONFUSION_SCATTER")
     monkeypatch.setenv("XCOLUMNS_CONFUSION_PRED_SIDE", "0")
     C = calculate_confusion_matrix(Td, Pd, skip_tn=True, dtype=torch.float64)
     assert np.allclose(np.stack([C.tp.cpu().numpy(), C.fp.cpu().numpy(), C.fn.cpu().numpy()]), got, rtol=1e-12, atol=1e-12)

@@ -61,6 +61,8 @@ SIGNATURES = {
     "xc_csr_rows_ascending": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xc_confusion_csr_pred_side": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xc_confusion_csr_match": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "xc_confusion_dense": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "xc_bca_gather_pred_eta": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,

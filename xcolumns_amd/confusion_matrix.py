@@ -117,8 +117,27 @@ def confusion_csr_device(t: D.DeviceCSR, p: D.DeviceCSR, keeps: bool = True) -> 
     # XCOLUMNS_CONFUSION_PRED_SIDE=0 disables.
     if (keeps and os.environ.get("XCOLUMNS_CONFUSION_PRED_SIDE", "1") != "0" and t.n > 0
             and items >= _PRED_SIDE_MIN_ITEMS and t.nnz > 2 * p.nnz and t.rows_ascending()):
-        out[2].copy_(t.column_sums())
         flag = torch.zeros(1, dtype=torch.int32, device=t.data.device)
+        # a 0/1 float32 prediction (what predict_* return): no global atomics at all -- match, then a counting sort + LDS
+        # sums of (label, y_true value) pairs (xc_scatter_sum_f32): 0.80 -> 0.3 ms at 1 M x 500 K
+        if (t.data.dtype == torch.float32 and p.data.dtype == torch.float32 and t.m <= 16384 * 2048
+                and os.environ.get("XCOLUMNS_CONFUSION_SCATTER", "1") != "0"):
+            val = torch.empty(max(1, p.nnz), dtype=torch.float32, device=t.data.device)
+            _lib.call("xc_confusion_csr_match", t.n, D.ptr(t.indptr), D.ptr(t.indices), D.ptr(t.data), D.ptr(p.indptr),
+                      D.ptr(p.indices), D.ptr(p.data), D.ptr(val), D.ptr(flag), D.stream())
+            nbytes = ctypes.c_int64(0)
+            _lib.call("xc_scatter_sum_workspace_bytes", int(p.nnz), t.m, ctypes.byref(nbytes))
+            ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=t.data.device)
+            pairs = torch.empty((t.m, 2), dtype=torch.float64, device=t.data.device)
+            _lib.call("xc_scatter_sum_f32", int(p.nnz), D.ptr(p.indices), D.ptr(val), t.m, 1, D.ptr(pairs), D.ptr(ws), D.stream())
+            out[0].copy_(pairs[:, 0])
+            out[1].copy_(pairs[:, 1])
+            torch.sub(t.column_sums(), out[0], out=out[2])
+            if int(flag.item()) == 0:
+                return out
+            out.zero_()
+            flag.zero_()
+        out[2].copy_(t.column_sums())
         _lib.call("xc_confusion_csr_pred_side", t.n, t.m, D.ptr(t.indptr), D.ptr(t.indices), D.ptr(t.data),
                   D.ptr(p.indptr), D.ptr(p.indices), D.ptr(p.data), t.code, D.ptr(out[0]), D.ptr(out[1]), D.ptr(out[2]),
                   D.ptr(flag), D.stream())
