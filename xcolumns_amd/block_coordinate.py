@@ -597,7 +597,13 @@ class BcaCsrEngine:
         """The reference's sequential semantics with a window of rows in flight: rows of at most 256 stored entries
         (longer rows and greedy first sweeps take the one-wavefront sweep).  XCOLUMNS_BCA_ORDERED=0 /
         `ordered=False` disables."""
-        return (self.ordered and not greedy and n_order > 1 and self.csr.n > 0 and int(self.csr.max_row_nnz) <= 256)
+        # float32 scores only: their sums in float64 are exact, so "committed record + the earlier rows' changes" is the
+        # number the sequential sweep holds whatever the order of the additions; with float64 scores every addition rounds,
+        # the statistics differ from the sequential ones in the last bit, and ill-conditioned gains (tn-based metrics with
+        # skip_tn) turn that into other decisions (the exact fuzz: 1 case in ~100): those take the one-wavefront sweep
+        # (`bca_ordered=True` forces it for float64 scores too)
+        return (self.ordered and not greedy and n_order > 1 and self.csr.n > 0 and int(self.csr.max_row_nnz) <= 256
+                and (self.csr.data.dtype == torch.float32 or getattr(self, "ordered_forced", False)))
 
     def _ordered_setup(self, orphans: Optional[torch.Tensor]):
         """Label directory of the ordered sweep: which labels get a dense table (a window holds many rows that store
@@ -687,17 +693,17 @@ class BcaCsrEngine:
         self.ordered_stats = {"iterations": int(status[2]), "windows": int(status[3]), "done": done, "error": err,
                               "barrier_us": status[4] / 100.0, "kernel_us": status[5] / 100.0, "rows_per_wave": int(status[6]),
                               "window": self._ord_wg * self._ord_waves * int(status[6]), "n_hot": d["n_hot"]}
-        if err == 1:
-            # a change list overflowed (more rows of one window changed a label than its list holds): the committed
-            # prefix stands, the one-wavefront sweep walks the rest of the order -- the same sweep, exactly
+        if err in (1, 3):
+            # a change list overflowed (more rows of one window changed a label than its list holds), or a window did not
+            # settle within the iteration limit: the committed prefix stands, the one-wavefront sweep walks the rest of the
+            # order -- the same sweep, exactly
             d["ws"].zero_()
             rest = (order if order is not None else torch.arange(n_order, dtype=torch.int32, device=self.dev))[done:]
             _lib.call("xc_bca_plan_sweep", self._plan_handle(), D.ptr(rest), int(n_order - done), D.ptr(self.orphans), 0, 1, 0,
                       0, D.ptr(self.changed), D.stream())
         elif err != 0:
             d["ws"].zero_()
-            raise RuntimeError(f"ordered BCA sweep failed (status {err}: "
-                               f"{'barrier timeout' if err == 2 else 'iteration limit'}) after {done} rows")
+            raise RuntimeError(f"ordered BCA sweep failed (status {err}: barrier timeout) after {done} rows")
         if self.orphans is not None:
             self._ord_dirs.pop(True, None)        # the directory with the orphans' allowance served its one sweep
         self._pack_dirty = True          # sel was rewritten without touching the packed copy
@@ -1373,6 +1379,7 @@ def _bc_csr(y_proba, gain_spec, utility_spec, k, metric_aggregation, n_u, maximi
                            deterministic=bca_deterministic)
         if bca_ordered is not None:
             eng.ordered = bool(bca_ordered)
+            eng.ordered_forced = bool(bca_ordered)
 
         log_info("  Initializing initial prediction ...", verbose)
         greedy = isinstance(init_y_pred, str) and init_y_pred == "greedy"

@@ -43,6 +43,10 @@ namespace xc {
 #endif
 #define XC_ORD_MAX_HOT 255
 #define XC_ORD_EPOCHS_PER_LAUNCH (1u << 20)
+// A window settles in 3-7 iterations; one that has not after 48 is not going to (decisions on a knife edge that the order of
+// a change list's float64 sum tips back and forth: ill-conditioned metrics on float64 scores, found by the exact fuzz): the
+// launch ends with status 3 before that window and the caller walks the rest of the order with one wavefront.
+#define XC_ORD_MAX_ITERATIONS 48
 // words of the sync block (zeroed before every launch)
 #define XC_ORD_BAR 0      /* barrier arrivals */
 #define XC_ORD_ABORT 1    /* != 0: leave (error code) */
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(XC_ORD_BLOCK) void bca_ordered_sweep_kernel(OrdPara
                 converged = true;
                 break;
             }
-            if (epoch >= epoch_end || t >= W + 2) { err = 3; break; }
+            if (epoch >= epoch_end || t >= W + 2 || t >= XC_ORD_MAX_ITERATIONS) { err = 3; break; }
             // ---- hot labels: prefix sums of this iteration's dense tables ----
             if (P.n_hot > 0) {
                 for (int h = blockIdx.x; h < P.n_hot; h += gridDim.x) ord_scan_hot<T>(P, wpar, h, W, epoch, s_w);

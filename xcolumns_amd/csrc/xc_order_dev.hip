@@ -574,7 +574,7 @@ __global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_grid_kernel(unsigned
 #pragma unroll
         for (int p = 0; p < XC_OG_PLANES; ++p) S.raw[wv * XC_OG_GROUP + p * 64 + lane] = raw[b0 + p * 64 + lane];
     }
-    unsigned bound_prev = 0xFFFFFFFFu, kept_total = 0u, last_publish = 0x80000000u;
+    unsigned bound_prev = 0xFFFFFFFFu, bound_round = 0u, kept_total = 0u, last_publish = 0x80000000u;
     int inner = 0, r = 0;
     bool gave_up = false, have_prev = false;
     for (;; ++r) {
@@ -646,8 +646,14 @@ __global__ __launch_bounds__(XC_OG_WAVES * 64) void og_walk_grid_kernel(unsigned
         //    expected count, a function of the bound, not marked exact -- and the one exact settle, plane after plane by one
         //    wavefront, happens when the bound is final.  Batches of the tail become final one round after each other.
         const bool tail = bound <= (unsigned)(XC_OG_WAVES * XC_OG_GROUP);
+        // Near the tail (bounds below 2^17: masks so small that every move of the bound changes many candidates' fate, a
+        // settle takes ~40 us and the bound keeps moving for 13-16 rounds) a batch whose bound still moved by more than 32
+        // since the last round does the same: an estimate now, the exact settle once the batches before have calmed down.
+        const unsigned moved_by = bound > bound_round ? bound - bound_round : bound_round - bound;
+        const bool restless = r > 0 && bound < (1u << 17) && moved_by > 32u;
+        bound_round = bound;
         unsigned publish;
-        if (tail && !final_now) {
+        if ((tail || restless) && !final_now) {
             publish = bound - og_expected_from(bound, (double)(XC_OG_WAVES * XC_OG_GROUP));
         } else {
             // -- settle the batch from that bound (unless it is the bound it was last settled from: same result)
