@@ -942,7 +942,7 @@ class _OrderWorkers:
         return done
 
 
-_DEVICE_WALK_NS_PER_ROW = 0.75     # the device generator: 0.72 ms per 1 M-row order (grid-wide rejection walk, csrc/xc_order_dev.hip)
+_DEVICE_WALK_NS_PER_ROW = 0.75     # the device generator: 0.64-0.72 ms per 1 M-row order (grid-wide rejection walk, csrc/xc_order_dev.hip)
 _order_choice = None
 
 
