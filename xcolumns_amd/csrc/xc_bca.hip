@@ -452,8 +452,31 @@ __global__ __launch_bounds__(XC_BLOCK) XC_SWEEP_OCC void bca_sweep_csr_kernel(Sw
                         neg_tn = tn + omd;
                         pos_tn = tn;
                     }
-                    g = metric_eval_t<false>(P.metric_fast, tpc + ed, fpc + omd, fn, pos_tn) -
-                        metric_eval_t<false>(P.metric_fast, tpc, fpc, fn + ed, neg_tn);
+                    if (P.metric_fast.base == XC_M_FBETA && !P.metric_fast.mixed) {
+                        // F-beta (the headline metric): psi(with) - psi(without) over ONE denominator.  With D = b2 (tp + fp) + tp +
+                        // fn + eta + eps and s = eta + (1 - eta) (the reference's 1 - eta is rounded to the scores' type, so s is 1 only
+                        // up to that rounding) the two values are (1 + b2)(tp + eta) / (D + b2 s) and (1 + b2) tp / D, so the gain is
+                        // (1 + b2)(eta D - b2 s tp) / (D (D + b2 s)): one reciprocal per candidate instead of two, and no cancellation
+                        // between two nearly equal quotients
+                        const double b2 = P.metric_fast.beta * P.metric_fast.beta;
+                        const double b2s = b2 * (ed + omd);
+                        const double den = (b2 * (tpc + fpc)) + tpc + (fn + ed) + P.metric_fast.epsilon;
+                        g = fdiv<false>((1.0 + b2) * (ed * den - b2s * tpc), den * (den + b2s));
+                    } else if (P.metric_fast.base == XC_M_JACCARD && !P.metric_fast.mixed) {
+                        // (tp + eta) / (D + 1 - eta) - tp / D with D = tp + fp + fn + eta + eps
+                        const double den = tpc + fpc + (fn + ed) + P.metric_fast.epsilon;
+                        g = fdiv<false>(ed * den - tpc * omd, den * (den + omd));
+                    } else if (P.metric_fast.base == XC_M_PRECISION && !P.metric_fast.mixed) {
+                        // (tp + eta) / (D + s) - tp / D with D = tp + fp + eps, s = eta + (1 - eta)
+                        const double den = tpc + fpc + P.metric_fast.epsilon, s1 = ed + omd;
+                        g = fdiv<false>(ed * den - tpc * s1, den * (den + s1));
+                    } else if (P.metric_fast.base == XC_M_RECALL && !P.metric_fast.mixed) {
+                        // (tp + eta) / D - tp / D with D = tp + fn + eta + eps (the row's eta is on one side or the other)
+                        g = fdiv<false>(ed, tpc + (fn + ed) + P.metric_fast.epsilon);
+                    } else {
+                        g = metric_eval_t<false>(P.metric_fast, tpc + ed, fpc + omd, fn, pos_tn) -
+                            metric_eval_t<false>(P.metric_fast, tpc, fpc, fn + ed, neg_tn);
+                    }
                 }
                 if (!P.maximize) g = -g;
                 key[c] = sortable_key(nan_to_neg_inf(g));
