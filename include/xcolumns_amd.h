@@ -617,6 +617,12 @@ int xc_order_dev_workspace_bytes(int64_t n, int64_t *bytes);
 int xc_order_dev_begin(void *workspace, const uint64_t *state_inc, int consumed, int64_t n, int32_t *order, void *stream);
 /* order_out <- one Generator.shuffle of order_in (int32[n] each, device, distinct); asynchronous on `stream`. */
 int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, int32_t *order_out, void *stream);
+/* The same in two halves, for two streams: the draw (candidate stream, rejection walk: the swap partners of all steps into
+ * set `slot` (0 / 1) of the workspace; advances the generator's position -- the next draw needs nothing else of this
+ * shuffle) and the apply (the Fisher-Yates swaps with the partners of `slot`).  The caller orders apply k behind draw k and
+ * draw k + 2 behind apply k (events). */
+int xc_order_dev_draw(void *workspace, int64_t n, int slot, void *stream);
+int xc_order_dev_apply(void *workspace, int64_t n, int slot, const int32_t *order_in, int32_t *order_out, void *stream);
 /* out8_host = {failure flag (0: every shuffle so far is numpy's), 32-bit draws consumed, shuffles, shader cycles and
  * 100 MHz ticks of the last rejection walk, its rounds and batches, walks redone by the one-wavefront fallback};
  * blocks on `stream`. */

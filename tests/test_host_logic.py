@@ -303,7 +303,8 @@ def test_wave_policy_rules():
         # a later sweep on skewed labels that the rule leaves fewer than 64 wavefronts runs exactly (the device-side loop
         # pauses for it: XC_CTRL_EXACT_BELOW)
         assert zs.sequential_below == 64 and zs.next(10_000) > 64 and zs.next(100) > 64 and zs.next(40_000) == 1
-        assert bc.WavePolicy(100_000, m=30_000, row_nnz=10, k=5).next(None) == p.next(None)          # short rows do not widen
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=20, k=5).next(None) == p.next(None)          # short rows do not widen
+        assert bc.WavePolicy(100_000, m=30_000, row_nnz=12, k=5).next(None) == 1                     # k above a third of a row: exact sweeps
         gf = bc.WavePolicy(150_000, m=670_000, row_nnz=50, k=5, parity="final")
         # "final" parity takes the whole GPU there: the width does not move the difference on such a shape (r02_c3_width.txt)
         assert not gf.sequential and gf.next(None) == gf.cap and gf.next(10) == gf.cap

@@ -144,6 +144,8 @@ SIGNATURES = {
     "xc_order_dev_workspace_bytes": (c_int, [c_int64, POINTER(c_int64)]),
     "xc_order_dev_begin": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "xc_order_dev_shuffle": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "xc_order_dev_draw": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    "xc_order_dev_apply": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "xc_order_dev_status": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
     "xc_order_dev_set_rounds": (c_int, [c_int]),
     "xc_order_dev_walk_trace": (c_int, [c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64), c_void_p]),

@@ -179,10 +179,12 @@ class WavePolicy:
                 # (3.7 rows per label; the fuzz of round 2, seed 1065), 11-27 wavefronts 1.3e-5 on 22 K x 10.5 K, k = 2
                 # (4.1; seed 3059): the exact sweep
                 self.fixed = 1
-            if 2.0 * max(1, int(k)) > float(row_nnz) and self.parity == "per_sweep" and not self.fixed:
-                # a budget of more than half of a row's candidates (35 K x 14 K, 12 entries per row, k = 7: the fuzz of
-                # round 2) is another shape whose trajectory nothing but its own sequence tracks: TWO wavefronts already
-                # sit 1-5e-5 from it, and nearly half of the rows still change in the second sweep
+            if 3.0 * max(1, int(k)) > float(row_nnz) and self.parity == "per_sweep" and not self.fixed:
+                # a budget of more than a THIRD of a row's candidates (35 K x 14 K, 12 entries per row, k = 7: the fuzz of
+                # round 2; half of a row until the fuzz of round 3 found 14 K x 5 K, 12 entries, k = 6 at 2.3e-5 with 7-29
+                # wavefronts and 34 K x 19 K, 12 entries, k = 5 at 1.1e-5 with 18-43) is another shape whose trajectory
+                # nothing but its own sequence tracks: TWO wavefronts already sit 1-5e-5 from it, and nearly half of the rows
+                # still change in the second sweep
                 self.fixed = 1
             full_width = False
             if per_label < 2.0 and self.parity == "final" and not self.fixed:
@@ -440,10 +442,9 @@ class BcaCsrEngine:
             self.shadow.zero_()
         self.colsum.zero_()
         if not greedy:
-            c = self.csr
-            if not self._scatter_sum(c.nnz, c.indices, c.data, self.colsum, pair=False):
-                _lib.call("xc_bca_colsum_csr", c.nnz, D.ptr(c.indices), D.ptr(c.data), c.code,
-                          D.ptr(self.colsum), D.stream())
+            # the column sums of y_proba depend on the matrix alone: kept with the DeviceCSR (a caller that holds on to its
+            # matrix -- another k, another metric -- pays the 50 M-entry scatter, 1.25 ms at 1 M x 500 K, once)
+            self.colsum.copy_(self.csr.column_sums())
             if self.comm is not None:
                 self.comm.all_reduce(self.colsum)
             self._expand_colsum()

@@ -887,7 +887,8 @@ int xc_order_dev_workspace_bytes(int64_t n, int64_t *bytes) {
     // header | raw[count + 2] | plane records[count / 64 + 256] | js[n] | head[n] | nxt[n] | root[n] | src[n] | history of the
     // grid-wide walk [64 rounds][batches]
     *bytes = 256 + xc::og_align((count + 2) * 4) + xc::og_align((count / 64 + 256) * 16) + 5 * xc::og_align(n * 4 + 4) +
-             xc::og_align((int64_t)(XC_OG_HIST_ROUNDS + 4) * (count / (XC_OG_WAVES * XC_OG_GROUP) + 1) * 8); // + 4 words of diagnostics per batch
+             xc::og_align((int64_t)(XC_OG_HIST_ROUNDS + 4) * (count / (XC_OG_WAVES * XC_OG_GROUP) + 1) * 8) + // + 4 words of diagnostics per batch
+             xc::og_align(n * 4 + 4);                                                                          // the second set of partners
     return XC_OK;
 }
 
@@ -909,53 +910,101 @@ int xc_order_dev_begin(void *workspace, const uint64_t *state_inc, int consumed,
     return XC_OK;
 }
 
-// One Generator.shuffle: order_out <- the shuffle of order_in (both int32[n] on the device, different buffers); the
-// generator position in the workspace advances.  Asynchronous on `stream`.
-int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, int32_t *order_out, void *stream) {
-    if (!workspace || n < 0 || (n > 0 && (!order_in || !order_out)) || order_in == order_out)
-        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_shuffle: bad argument");
-    if (n == 0) return XC_OK;
-    hipStream_t st = xc::as_stream(stream);
-    if (n == 1) {
-        XC_HIP_TRY(hipMemcpyAsync(order_out, order_in, 4, hipMemcpyDeviceToDevice, st));
-        return XC_OK;
-    }
+// The two halves of one Generator.shuffle, for two streams (utils.DeviceNumpyOrders): the DRAW -- candidate stream, rejection
+// walk, the partners js[slot] of all steps; it advances the generator's position in the workspace, and the draw of the NEXT
+// shuffle needs nothing else of this one -- and the APPLY: the Fisher-Yates swaps with those partners, order_out <- the
+// shuffle of order_in.  slot 0 / 1: two sets of partners, so that the next draw may run while this apply still reads its set
+// (the caller orders draw k + 2 behind apply k).
+struct OgLayout {
+    unsigned long long *hdr;
+    unsigned *raw;
+    xc::OgRec *recs;
+    unsigned *js[2];
+    int *head, *nxt, *root, *src;
+    unsigned long long *hist;
+    int64_t count;
+    unsigned batches;
+};
+
+static int og_layout(void *workspace, int64_t n, OgLayout &L) {
     int64_t count = 0;
     int rc = xc_order_dev_candidates(n, &count);
     if (rc) return rc;
     count += 2;
     char *w = static_cast<char *>(workspace);
-    unsigned long long *hdr = reinterpret_cast<unsigned long long *>(w);
+    L.hdr = reinterpret_cast<unsigned long long *>(w);
     char *q = w + 256;
-    unsigned *raw = reinterpret_cast<unsigned *>(q);
+    L.raw = reinterpret_cast<unsigned *>(q);
     q += xc::og_align(count * 4);
-    xc::OgRec *recs = reinterpret_cast<xc::OgRec *>(q);
+    L.recs = reinterpret_cast<xc::OgRec *>(q);
     q += xc::og_align(((count - 2) / 64 + 256) * 16);
     const int64_t seg = xc::og_align(n * 4 + 4);
-    unsigned *js = reinterpret_cast<unsigned *>(q);
-    int *head = reinterpret_cast<int *>(q + seg), *nxt = reinterpret_cast<int *>(q + 2 * seg);
-    int *root = reinterpret_cast<int *>(q + 3 * seg), *src = reinterpret_cast<int *>(q + 4 * seg);
-    unsigned long long *hist = reinterpret_cast<unsigned long long *>(q + 5 * seg);
-    const unsigned batches = (unsigned)((count - 2) / (XC_OG_WAVES * XC_OG_GROUP)); // whole batches behind the first candidate (raw index 0 or 1)
+    L.js[0] = reinterpret_cast<unsigned *>(q);
+    L.head = reinterpret_cast<int *>(q + seg);
+    L.nxt = reinterpret_cast<int *>(q + 2 * seg);
+    L.root = reinterpret_cast<int *>(q + 3 * seg);
+    L.src = reinterpret_cast<int *>(q + 4 * seg);
+    L.hist = reinterpret_cast<unsigned long long *>(q + 5 * seg);
+    q += 5 * seg + xc::og_align((int64_t)(XC_OG_HIST_ROUNDS + 4) * ((count - 2) / (XC_OG_WAVES * XC_OG_GROUP) + 1) * 8);
+    L.js[1] = reinterpret_cast<unsigned *>(q);
+    L.count = count;
+    L.batches = (unsigned)((count - 2) / (XC_OG_WAVES * XC_OG_GROUP)); // whole batches behind the first candidate (raw index 0 or 1)
+    return XC_OK;
+}
+
+int xc_order_dev_draw(void *workspace, int64_t n, int slot, void *stream) {
+    if (!workspace || n < 2 || slot < 0 || slot > 1) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_draw: bad argument");
+    hipStream_t st = xc::as_stream(stream);
+    OgLayout L;
+    int rc = og_layout(workspace, n, L);
+    if (rc) return rc;
     int max_rounds = XC_OG_HIST_ROUNDS;
     if (xc::g_og_rounds > 0 && xc::g_og_rounds < XC_OG_HIST_ROUNDS) max_rounds = xc::g_og_rounds;
+    hipLaunchKernelGGL(xc::og_raw_kernel, dim3((unsigned)((L.count / 16 + 256) / 256)), dim3(256), 0, st, L.hdr, L.raw, (long long)L.count);
+    const bool grid = L.batches >= 2 && xc::g_og_rounds >= 0;
+    if (grid)
+        hipLaunchKernelGGL(xc::og_walk_grid_kernel, dim3(L.batches), dim3(XC_OG_WAVES * 64), 0, st, L.hdr, L.raw, (long long)n, L.recs, L.hist,
+                           max_rounds, L.hist + (size_t)XC_OG_HIST_ROUNDS * L.batches);
+    hipLaunchKernelGGL(xc::og_walk_kernel, dim3(1), dim3(64), 0, st, L.hdr, L.raw, (long long)L.count, (long long)n, L.recs, grid ? 1 : 0,
+                       L.batches);
+    hipLaunchKernelGGL(xc::og_compact_kernel, dim3((unsigned)((L.count / 64 + 4) / 4)), dim3(256), 0, st, L.hdr, L.raw, L.recs, (long long)n,
+                       L.js[slot]);
+    XC_CHECK_LAUNCH("order generator kernels (draw)");
+    return XC_OK;
+}
+
+int xc_order_dev_apply(void *workspace, int64_t n, int slot, const int32_t *order_in, int32_t *order_out, void *stream) {
+    if (!workspace || n < 2 || slot < 0 || slot > 1 || !order_in || !order_out || order_in == order_out)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_apply: bad argument");
+    hipStream_t st = xc::as_stream(stream);
+    OgLayout L;
+    int rc = og_layout(workspace, n, L);
+    if (rc) return rc;
     const long long steps = n - 1;
     const unsigned gb = (unsigned)((steps + 255) / 256);
-    XC_HIP_TRY(hipMemsetAsync(head, 0xff, (size_t)n * 4, st));
-    hipLaunchKernelGGL(xc::og_raw_kernel, dim3((unsigned)((count / 16 + 256) / 256)), dim3(256), 0, st, hdr, raw, (long long)count);
-    const bool grid = batches >= 2 && xc::g_og_rounds >= 0;
-    if (grid)
-        hipLaunchKernelGGL(xc::og_walk_grid_kernel, dim3(batches), dim3(XC_OG_WAVES * 64), 0, st, hdr, raw, (long long)n, recs, hist, max_rounds,
-                           hist + (size_t)XC_OG_HIST_ROUNDS * batches);
-    hipLaunchKernelGGL(xc::og_walk_kernel, dim3(1), dim3(64), 0, st, hdr, raw, (long long)count, (long long)n, recs, grid ? 1 : 0, batches);
-    hipLaunchKernelGGL(xc::og_compact_kernel, dim3((unsigned)((count / 64 + 4) / 4)), dim3(256), 0, st, hdr, raw, recs, (long long)n, js);
-    hipLaunchKernelGGL(xc::og_lists_kernel, dim3(gb), dim3(256), 0, st, steps, js, head, nxt);
-    hipLaunchKernelGGL(xc::og_links_kernel, dim3(gb), dim3(256), 0, st, (long long)n, js, head, nxt, root, src);
-    for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(xc::og_jump_kernel, dim3(gb), dim3(256), 0, st, steps, root);
-    hipLaunchKernelGGL(xc::og_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long long)n, root, src, head, nxt,
-                       order_in, order_out, hdr);
-    XC_CHECK_LAUNCH("order generator kernels");
+    XC_HIP_TRY(hipMemsetAsync(L.head, 0xff, (size_t)n * 4, st));
+    hipLaunchKernelGGL(xc::og_lists_kernel, dim3(gb), dim3(256), 0, st, steps, L.js[slot], L.head, L.nxt);
+    hipLaunchKernelGGL(xc::og_links_kernel, dim3(gb), dim3(256), 0, st, (long long)n, L.js[slot], L.head, L.nxt, L.root, L.src);
+    for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(xc::og_jump_kernel, dim3(gb), dim3(256), 0, st, steps, L.root);
+    hipLaunchKernelGGL(xc::og_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long long)n, L.root, L.src, L.head, L.nxt,
+                       order_in, order_out, L.hdr);
+    XC_CHECK_LAUNCH("order generator kernels (apply)");
     return XC_OK;
+}
+
+// One Generator.shuffle on one stream: order_out <- the shuffle of order_in (both int32[n] on the device, different buffers);
+// the generator position in the workspace advances.  Asynchronous on `stream`.
+int xc_order_dev_shuffle(void *workspace, int64_t n, const int32_t *order_in, int32_t *order_out, void *stream) {
+    if (!workspace || n < 0 || (n > 0 && (!order_in || !order_out)) || order_in == order_out)
+        return xc::fail_arg(XC_ERR_BAD_ARG, "xc_order_dev_shuffle: bad argument");
+    if (n == 0) return XC_OK;
+    if (n == 1) {
+        XC_HIP_TRY(hipMemcpyAsync(order_out, order_in, 4, hipMemcpyDeviceToDevice, xc::as_stream(stream)));
+        return XC_OK;
+    }
+    int rc = xc_order_dev_draw(workspace, n, 0, stream);
+    if (rc) return rc;
+    return xc_order_dev_apply(workspace, n, 0, order_in, order_out, stream);
 }
 
 // Diagnostics of the last grid-wide walk: per batch {start, end (100 MHz ticks since the shuffle began), ticks waiting <<

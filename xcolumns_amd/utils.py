@@ -315,12 +315,15 @@ class DeviceNumpyOrders:
         self.ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=device)
         self.bufs = [torch.empty(max(1, self.n), dtype=torch.int32, device=device) for _ in range(self.DEPTH)]
         self.side = torch.cuda.Stream(device=device) if self.ahead > 0 else None
+        self.side_b = torch.cuda.Stream(device=device) if self.ahead > 0 else None
+        self._applied = {}          # shuffle number -> event of its apply half
         if self.side is not None:
-            # the side stream works on these tensors: the allocator must not hand their memory to anybody else before
+            # the side streams work on these tensors: the allocator must not hand their memory to anybody else before
             # that work has finished, even if this object is dropped without finish()
-            self.ws.record_stream(self.side)
-            for b in self.bufs:
-                b.record_stream(self.side)
+            for st in (self.side, self.side_b):
+                self.ws.record_stream(st)
+                for b in self.bufs:
+                    b.record_stream(st)
         mask = (1 << 64) - 1
         words = (ctypes.c_uint64 * 4)(base >> 64, base & mask, self._inc >> 64, self._inc & mask)
         with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
@@ -337,28 +340,43 @@ class DeviceNumpyOrders:
         try:
             if self.side is not None:
                 self.side.synchronize()
+                self.side_b.synchronize()
         except Exception:
             pass
 
     def _generate(self):
-        """Enqueue shuffle number generated + 1: bufs[k % DEPTH] <- shuffle of bufs[(k - 1) % DEPTH]."""
+        """Enqueue shuffle number generated + 1: bufs[k % DEPTH] <- shuffle of bufs[(k - 1) % DEPTH].  On side streams in two
+        halves: the draw (rejection walk, the chain the NEXT shuffle waits for) on one, the apply (Fisher-Yates swaps) on the
+        other -- the apply of shuffle k runs beside the draw of shuffle k + 1."""
         import torch
 
         from . import _device as D
         from . import _lib
         k = self.generated + 1
-        with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
-            if self.side is not None:
-                # the buffer held order k - DEPTH: its sweep was enqueued before order k - DEPTH + 1 was handed out
-                ev = self._free.pop(k - self.DEPTH + 1, None)
-                if ev is not None:
-                    self.side.wait_event(ev)
-            _lib.call("xc_order_dev_shuffle", D.ptr(self.ws), self.n, D.ptr(self.bufs[(k - 1) % self.DEPTH]),
-                      D.ptr(self.bufs[k % self.DEPTH]), D.stream())
-            if self.side is not None:
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-                self._done[k] = ev
+        src, dst = self.bufs[(k - 1) % self.DEPTH], self.bufs[k % self.DEPTH]
+        if self.side is None or self.n < 2:
+            _lib.call("xc_order_dev_shuffle", D.ptr(self.ws), self.n, D.ptr(src), D.ptr(dst), D.stream())
+            self.generated = k
+            return
+        slot = k & 1
+        with torch.cuda.stream(self.side):
+            ev = self._applied.pop(k - 2, None)          # the partners of `slot` were last read by the apply of shuffle k - 2
+            if ev is not None:
+                self.side.wait_event(ev)
+            _lib.call("xc_order_dev_draw", D.ptr(self.ws), self.n, slot, D.stream())
+            drawn = torch.cuda.Event()
+            drawn.record(self.side)
+        with torch.cuda.stream(self.side_b):
+            self.side_b.wait_event(drawn)
+            # the buffer held order k - DEPTH: its sweep was enqueued before order k - DEPTH + 1 was handed out
+            ev = self._free.pop(k - self.DEPTH + 1, None)
+            if ev is not None:
+                self.side_b.wait_event(ev)
+            _lib.call("xc_order_dev_apply", D.ptr(self.ws), self.n, slot, D.ptr(src), D.ptr(dst), D.stream())
+            ev = torch.cuda.Event()
+            ev.record(self.side_b)
+            self._done[k] = ev
+            self._applied[k] = ev
         self.generated = k
 
     def next(self):
@@ -385,6 +403,8 @@ class DeviceNumpyOrders:
         from . import _device as D
         from . import _lib
         out = (ctypes.c_int64 * 8)()
+        if self.side is not None:
+            self.side_b.synchronize()      # (the apply half may flag a failed shuffle too)
         with torch.cuda.stream(self.side) if self.side is not None else _nullcontext():
             _lib.call("xc_order_dev_status", D.ptr(self.ws), out, D.stream())
         self.last_walk = {"cycles": int(out[3]), "us": int(out[4]) / 100.0, "rounds": int(out[5]), "batches": int(out[6]),
