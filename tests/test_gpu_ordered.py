@@ -50,10 +50,13 @@ def _run(Y, k, oref, base, skip_tn=True, sweeps=3, entry="predict_using_bc_with_
 @pytest.mark.parametrize("zipf", [False, True])
 @pytest.mark.parametrize("workgroups", [None, 3])
 def test_ordered_equals_sequential_oracle(oref, monkeypatch, zipf, workgroups):
-    """20 K x 3 K, macro-F1: one window per 4096 rows (5 windows) and, with 3 workgroups, 48-row windows (417
-    windows); Zipf popularity puts the head labels on the dense tables."""
+    """20 K x 3 K, macro-F1: windows of 7680 rows (3 windows) and, with 3 workgroups, 96-row windows (209 windows); with
+    Zipf popularity the head labels are put on the dense tables (from 48 readers per window on: the default, 1600,
+    leaves this matrix to the change lists alone -- that form is the Zipf cases of the other tests)."""
     if workgroups:
         monkeypatch.setenv("XCOLUMNS_BCA_ORD_WORKGROUPS", str(workgroups))
+    if zipf:
+        monkeypatch.setenv("XCOLUMNS_BCA_ORD_HOT_READERS", "48")
     Y = _csr(20000, 3000, 30, 11 + int(zipf), zipf=zipf)
     _run(Y, 5, oref, oref.FBETA, sweeps=3)
 

@@ -646,8 +646,14 @@ class BcaCsrEngine:
         if orphans is not None:
             counts = counts + torch.bincount(orphans[orphans >= 0], minlength=c.m)
         readers = counts.to(torch.float64) * (float(W) / float(max(1, c.n)))     # expected rows of a window that store the label
-        # dense tables: a list of L entries read by L rows is L^2 entry reads, a table W slots scanned once
-        hot_min = float(os.environ.get("XCOLUMNS_BCA_ORD_HOT_READERS", "48"))
+        # dense tables: a list of L entries read by L rows is L^2 entry reads, a table W slots scanned once -- but ANY table
+        # costs the window a second barrier and a scan per iteration (~25 us), and the lists win far beyond the point where
+        # L^2 = W: measured at 100 K x 30 K and 150 K x 670 K with Zipf(1) labels, top-k and random starts
+        # (profiles/r03_ordered_hot_threshold.txt), first sweep 6.1 / 8.2 ms with tables from 48 readers on (255 tables), 4.2 /
+        # 5.5 ms from 400 (81 / 56 tables), 3.2 / 4.0 ms with none.  Tables remain for labels that a fifth of a window's rows
+        # store (1600 readers of 7680): there a window in which most of those rows change the label would be 10^6-10^7 entry
+        # reads per iteration.
+        hot_min = float(os.environ.get("XCOLUMNS_BCA_ORD_HOT_READERS", "1600"))
         n_hot = int(min(255, int((readers >= hot_min).sum().item())))
         if os.environ.get("XCOLUMNS_BCA_ORD_HOT", "1") == "0":
             n_hot = 0
