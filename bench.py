@@ -659,7 +659,7 @@ def api_call_leg(Y, sweeps):
     res["device_resident"] = timed(Yd, sweeps)
     by = {}
     from xcolumns_amd.block_coordinate import _orders_on_device
-    res["order_default_on_this_machine"] = "gpu" if _orders_on_device() else "host threads"
+    res["order_default_on_this_machine"] = "gpu" if _orders_on_device(n) else "host threads"
     for k_sweeps in sorted({10, 20}):
         row = {"default": timed(Yd, k_sweeps)}
         for name, flag in (("numpy_stream_on_gpu", "1"), ("numpy_stream_on_host_threads", "0")):

@@ -949,21 +949,24 @@ class _OrderWorkers:
         return done
 
 
-_DEVICE_WALK_NS_PER_ROW = 0.75     # the device generator: 0.64-0.72 ms per 1 M-row order (grid-wide rejection walk, csrc/xc_order_dev.hip)
+_DEVICE_WALK_NS_PER_ROW = 0.25     # the device generator: 0.28 ms + 0.25 ns per row and order (csrc/xc_order_dev.hip; tools/order_walk_trace.py)
+_DEVICE_ORDER_NS_FIXED = 280_000.0
 _order_choice = None
 
 
-def _orders_on_device() -> bool:
-    """Where numpy's visiting-order stream is generated for large matrices: XCOLUMNS_ORDER_DEVICE=1 / 0 forces the GPU
-    / the host's two worker threads; by default whichever is faster on THIS machine -- the device generator takes the
-    same 0.75 ns per row everywhere, the host's sequential walk 1.3 ns per row on a fast idle core and 4 ns and more on
-    a slow or busy one (measured once per process on 256 K rows): in practice the device, unless it is not usable."""
+def _orders_on_device(n: int = 1_000_000) -> bool:
+    """Where numpy's visiting-order stream is generated for a matrix of n rows: XCOLUMNS_ORDER_DEVICE=1 / 0 forces the GPU /
+    the host's two worker threads; by default whichever is faster on THIS machine for THIS size.  The device generator takes
+    0.28 ms + 0.25 ns per row (its rejection walk is a chain of rounds whatever the size: 0.28 / 0.37 / 0.64 / 1.1 ms at 50 K
+    / 100 K / 1 M / 3 M rows), the host's sequential walk 1.3 ns per row on a fast idle core and 4 ns and more on a slow or
+    busy one (measured once per process on 256 K rows): small matrices on a fast host stay on the host (100 K rows: 10 sweeps
+    in 2.4 ms against 6.1), large ones and slow hosts go to the GPU."""
     global _order_choice
     env = os.environ.get("XCOLUMNS_ORDER_DEVICE")
     if env is not None:
         return env != "0"
     if _order_choice is None:
-        choice = True
+        host_ns = float("inf")
         try:
             from .utils import Pcg64Shuffler
             if Pcg64Shuffler.usable():
@@ -978,11 +981,10 @@ def _orders_on_device() -> bool:
                     sh.apply(js)
                 swaps = (_time.perf_counter() - t0) / 3
                 host_ns = max(draws, swaps) / (1 << 18) * 1e9
-                choice = host_ns > 0.9 * _DEVICE_WALK_NS_PER_ROW
         except Exception:
-            choice = True
-        _order_choice = choice
-    return _order_choice
+            host_ns = float("inf")
+        _order_choice = host_ns
+    return _order_choice * float(n) > 0.9 * (_DEVICE_ORDER_NS_FIXED + _DEVICE_WALK_NS_PER_ROW * float(n))
 
 
 class _OrderSource:
@@ -1022,7 +1024,7 @@ class _OrderSource:
                 self._fast = Pcg64Shuffler(self.rng, n)
         # numpy's stream generated ON the GPU (csrc/xc_order_dev.hip, utils.DeviceNumpyOrders): no host work per sweep
         self._devgen = None
-        if backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS and _orders_on_device():
+        if backend == "numpy" and shuffle and n >= _ORDER_PREFETCH_ROWS and _orders_on_device(n):
             from .utils import DeviceNumpyOrders
             if DeviceNumpyOrders.usable(dev):
                 self._devgen = DeviceNumpyOrders(self.rng, n, dev, limit=self.limit)
