@@ -656,7 +656,7 @@ def api_call_leg(Y, sweeps):
                                       "whichever is faster on the machine (block_coordinate._orders_on_device)"}
     Yd = D.DeviceCSR.from_scipy(Y)
     res["host_csr_matrix"] = timed(Y, sweeps, reps=3)
-    res["device_resident"] = timed(Yd, sweeps)
+    timed(Yd, sweeps, reps=2)        # settle after the uploads of the leg above (its first calls scattered: 10-23 ms for a 10 ms call)
     by = {}
     from xcolumns_amd.block_coordinate import _orders_on_device
     res["order_default_on_this_machine"] = "gpu" if _orders_on_device(n) else "host threads"
@@ -671,6 +671,7 @@ def api_call_leg(Y, sweeps):
         row["torch_randperm"] = timed(Yd, k_sweeps, reps=3, order_backend="device")
         by[str(k_sweeps)] = row
     res["device_resident_by_sweeps"] = by
+    res["device_resident"] = by[str(sweeps)]["default"] if str(sweeps) in by else timed(Yd, sweeps)
     return res
 
 

@@ -314,8 +314,11 @@ class DeviceNumpyOrders:
         _lib.call("xc_order_dev_workspace_bytes", self.n, ctypes.byref(nbytes))
         self.ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=device)
         self.bufs = [torch.empty(max(1, self.n), dtype=torch.int32, device=device) for _ in range(self.DEPTH)]
-        self.side = torch.cuda.Stream(device=device) if self.ahead > 0 else None
-        self.side_b = torch.cuda.Stream(device=device) if self.ahead > 0 else None
+        # The two side streams are made ONCE per device, with high priority: torch hands out pooled streams round robin and
+        # ROCm maps them onto a few hardware queues -- every other call got a pair that shared a queue with the sweeps'
+        # stream and lost the overlap (10 sweeps: 10 / 14.5 / 10 / 14.5 ms, call after call); priority streams have queues of
+        # their own.
+        self.side, self.side_b = self._side_streams(device) if self.ahead > 0 else (None, None)
         self._applied = {}          # shuffle number -> event of its apply half
         if self.side is not None:
             # the side streams work on these tensors: the allocator must not hand their memory to anybody else before
@@ -335,6 +338,16 @@ class DeviceNumpyOrders:
         self._free = {}             # order number -> event on the consumer's stream recorded when the NEXT order was handed out
         for _ in range(min(self.ahead, self.limit)):
             self._generate()
+
+    _streams = {}
+
+    @classmethod
+    def _side_streams(cls, device):
+        import torch
+        key = torch.device(device).index or 0
+        if key not in cls._streams:
+            cls._streams[key] = (torch.cuda.Stream(device=device, priority=-1), torch.cuda.Stream(device=device, priority=-1))
+        return cls._streams[key]
 
     def __del__(self):
         try:
