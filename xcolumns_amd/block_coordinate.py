@@ -1104,7 +1104,7 @@ class _OrderSource:
             di = torch.device(self.dev).index or 0
             side = res.get(di)
             if side is None:
-                side = res[di] = torch.cuda.Stream(device=self.dev)
+                side = res[di] = torch.cuda.Stream(device=self.dev, priority=-1)   # (a queue of its own: see utils.DeviceNumpyOrders)
             slots = _ORDER_PREFETCH_DEPTH + 1      # one being filled, DEPTH - 1 queued, one in the consumer's hands
             key = (di, self.n)
             if key not in res:
