@@ -439,7 +439,9 @@ def worker(args):
         med = _median(el)
         n_local, n_global = main["n_local"], main["n_global"]
         roof = {"kernel": "bca_sweep_csr_kernel<float,1,false,true,true,true,%s> (one launch = one sweep of the rank's rows, "
-                          "from-scratch recompute fused)" % ("true" if main["hot"] else "false"),
+                          "from-scratch recompute fused%s)" % ("true" if main["hot"] else "false",
+                                                              "; N > 1: a sweep is walked in parts with exchanges of the ranks' changes in between -- "
+                                                              "the timed span runs from the first part's dispatch to the end of the last one" if world > 1 else ""),
                 "bound": "hbm"}
         if main["kernel_ms"]:
             roof.update(roofline_of(main["kernel_ms"], n_local))

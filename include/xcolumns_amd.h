@@ -336,6 +336,10 @@ int xc_event_create(void **ev);
 int xc_event_destroy(void *ev);
 int xc_event_elapsed_ms(void *start, void *stop, float *ms_host);
 int xc_bca_time_next_sweep(void *start, void *stop);
+/* The event pair pending from xc_bca_time_next_sweep spans the next `launches` sweep launches instead of one: row shards walk
+ * a sweep in parts with exchanges in between (start rides on the first part's dispatch, stop on the last one's).  No-op
+ * when no pair is pending. */
+int xc_bca_time_span(int launches);
 
 /* How a concurrent sweep guards a row that CHANGES its prediction against other rows in flight
  * that change the same labels (process-wide switch, mainly for studies):

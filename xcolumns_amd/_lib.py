@@ -132,6 +132,7 @@ SIGNATURES = {
     "xc_event_destroy": (c_int, [c_void_p]),
     "xc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_float)]),
     "xc_bca_time_next_sweep": (c_int, [c_void_p, c_void_p]),
+    "xc_bca_time_span": (c_int, [c_int]),
     "xc_bca_state_unpack": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     "xc_bca_sweep_dense": (c_int, [c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,

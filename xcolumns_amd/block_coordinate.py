@@ -806,6 +806,7 @@ class BcaCsrEngine:
                 parts = max(min(segments, fit), min(segments, min_exchanges(self.comm.world)))
             self.exchanges_used[-1] = parts
             bounds = [n * s // parts for s in range(parts + 1)]
+            _lib.call("xc_bca_time_span", int(parts))     # (bench.py's event pair, if one is pending, spans all the parts)
             pending = None
             for s in range(parts):
                 _lib.call("xc_bca_plan_sweep_pipelined", self._plan_handle(), D.ptr(order), bounds[s],

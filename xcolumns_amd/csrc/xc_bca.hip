@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(XC_BLOCK) void exchange_step_kernel(int64_t n, floa
 static unsigned long long *g_stamp_buffer = nullptr; // set by xc_debug_set_stamp_buffer
 // one-shot HIP events recorded tightly around the NEXT sweep launch (xc_bca_time_next_sweep)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local int g_ev_span = 1; // sweep launches the pending event pair spans (xc_bca_time_span)
 static int g_validate = 2;                           // xc_bca_set_validation: 2 = commit protocol
 static int g_acc_delta = 1;                          // xc_bca_set_acc_delta: pipelined sweeps push changes instead of rebuilding acc
 static float g_conflict_rel = 1.0f / 512.0f;         // xc_bca_set_tuning
@@ -1134,12 +1135,20 @@ static float g_hot_unpublished = 0.05f;              // xc_bca_set_tuning: share
 template <typename T, int CH, bool EXACT, bool HAS_ORDER, bool SHADOW, bool PACKED, bool HOT>
 static void launch_sweep_one(const SweepParams<T> &P, hipStream_t st) {
     const int blocks = (P.n_waves + 3) / 4;
-    if (g_ev_start && g_ev_stop) {
+    if (g_ev_stop) {
         // start / stop events attached to the dispatch itself: the measured span is the
-        // kernel, not the kernel plus the dispatch gap an event pair around it would add
+        // kernel, not the kernel plus the dispatch gap an event pair around it would add.  A sweep that row shards walk in
+        // parts (xc_bca_time_span): the start event rides on the first part's launch, the stop event on the last one's
+        const bool last = g_ev_span <= 1;
         hipExtLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>), dim3(blocks),
-                              dim3(XC_BLOCK), 0, st, g_ev_start, g_ev_stop, 0, P);
-        g_ev_start = g_ev_stop = nullptr;
+                              dim3(XC_BLOCK), 0, st, g_ev_start, last ? g_ev_stop : nullptr, 0, P);
+        g_ev_start = nullptr;
+        if (last) {
+            g_ev_stop = nullptr;
+            g_ev_span = 1;
+        } else {
+            --g_ev_span;
+        }
     } else {
         hipLaunchKernelGGL((bca_sweep_csr_kernel<T, CH, EXACT, HAS_ORDER, SHADOW, PACKED, HOT>), dim3(blocks),
                            dim3(XC_BLOCK), 0, st, P);
@@ -1442,6 +1451,13 @@ int xc_event_elapsed_ms(void *start, void *stop, float *ms_host) {
 int xc_bca_time_next_sweep(void *start, void *stop) {
     xc::g_ev_start = static_cast<hipEvent_t>(start);
     xc::g_ev_stop = static_cast<hipEvent_t>(stop);
+    xc::g_ev_span = 1;
+    return XC_OK;
+}
+
+int xc_bca_time_span(int launches) {
+    if (launches < 1) return xc::fail_arg(XC_ERR_BAD_ARG, "xc_bca_time_span: launches < 1");
+    if (xc::g_ev_stop) xc::g_ev_span = launches;
     return XC_OK;
 }
 
