@@ -1,3 +1,6 @@
+"""Call after call: wall time of the public BCA call at the north-star size (10, 10, 20 sweeps, ten calls each) with the order
+generator's walk diagnostics -- how profiles/r03_api_call_timing.txt's alternating 10 / 14.5 ms calls were found (pooled side
+streams sharing a hardware queue with the sweeps' stream)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())

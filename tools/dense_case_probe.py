@@ -1,3 +1,6 @@
+"""Two cases of tests/studies/fuzz_exact.py replayed with details (dense exact mode against the oracle): seed 40397, a float64
+minimisation driven to a utility of 1e-10 (other zero-probability labels in 12 rows, utilities equal), and seed 30332, a
+tn-based metric with skip_tn (ill-conditioned)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.getcwd())

@@ -1,3 +1,5 @@
+"""The ordered parallel sweep from a random and from the top-k start on Zipf(1) workloads: kernel time per sweep, iterations,
+hot tables -- run with XCOLUMNS_BCA_ORD_HOT_READERS = 48 and 1600 for profiles/r03_ordered_hot_threshold.txt."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
