@@ -631,7 +631,7 @@ int xc_order_dev_apply(void *workspace, int64_t n, int slot, const int32_t *orde
  * 100 MHz ticks of the last rejection walk, its rounds and batches, walks redone by the one-wavefront fallback};
  * blocks on `stream`. */
 int xc_order_dev_status(void *workspace, int64_t *out8_host, void *stream);
-/* Test knob: rounds the grid-wide rejection walk may take (0 = default, 64; 18-25 are needed).  With too few it gives up and
+/* Test knob: rounds the grid-wide rejection walk may take (0 = default, 96; 16-45 are needed).  With too few it gives up and
  * the one-wavefront walk behind it redoes the shuffle: the same permutation, ~8 ms per million rows.  Negative: the
  * one-wavefront walk only. */
 int xc_order_dev_set_rounds(int rounds);

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void og_walk_kernel(unsigned long long *hdr, co
 // The workgroup in which the walk ends stages the generator's new position; og_walk_kernel (one wavefront, behind this
 // launch) commits it -- or, if this kernel gave up (rounds exhausted, a wait that timed out: never observed), walks the
 // shuffle itself: the result is exact whatever happens here.
-#define XC_OG_HIST_ROUNDS 64
+#define XC_OG_HIST_ROUNDS 96 /* 26 rounds at 1 M rows, 33 at 10 M, 43 at 20 M (tools/order_walk_trace.py) */
 #define XC_OG_SPIN_LIMIT (1u << 21) /* polls of ~2 us each */
 
 __device__ __forceinline__ unsigned long long og_ld64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1026,7 +1026,7 @@ int xc_order_dev_walk_trace(void *workspace, int64_t n, int64_t *out, int64_t *b
     return XC_OK;
 }
 
-// Test knob: rounds the grid-wide walk may take (0 = default, 64).  With 1 or 2 it gives up on a large shuffle and the
+// Test knob: rounds the grid-wide walk may take (0 = default, 96).  With 1 or 2 it gives up on a large shuffle and the
 // one-wavefront walk behind it redoes the shuffle: same result.  Negative: the one-wavefront walk only.
 int xc_order_dev_set_rounds(int rounds) {
     xc::g_og_rounds = rounds;
