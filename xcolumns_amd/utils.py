@@ -81,13 +81,17 @@ def random_at_k_csr(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[i
     if seed is not None:
         random.seed(seed)
     indices = np.empty(n * k, dtype=np.int32)
-    base = np.arange(m, dtype=np.int32)
+    randint = random.randint
     for i in range(n):
-        index = base.copy()
+        # the partial Fisher-Yates shuffle of 0 .. m-1 (swap position t with a random position j >= t, t = 0 .. k-1) on the few
+        # positions it touches: a copy of the m-vector per row was 400 GB of memory traffic at 150 K x 670 K (5-9 s)
+        moved = {}
+        row = i * k
         for t in range(k):
-            j = random.randint(t, m - 1)
-            index[t], index[j] = index[j], index[t]
-        indices[i * k:(i + 1) * k] = index[:k]
+            j = randint(t, m - 1)
+            vt, vj = moved.get(t, t), moved.get(j, j)
+            moved[j] = vt
+            indices[row + t] = vj          # position t is final: later steps swap positions > t only
     indptr = (np.arange(n + 1, dtype=np.int64) * k).astype(np.int32)
     return construct_csr_matrix(np.ones(n * k, dtype=np.float32).astype(dtype), indices, indptr,
                                 dtype=dtype, shape=shape, sort_indices=True)
