@@ -350,3 +350,26 @@ def test_host_shuffle_is_numpys_stream():
             assert js.dtype == np.uint32 and js.size == max(0, n - 1)
             assert np.array_equal(halves.apply(js), ref2), (seed, n, sweep)
         assert c.random(3).tolist() == d.random(3).tolist()
+
+
+def test_random_at_k_csr_vectorised_is_the_loop():
+    """utils.random_at_k_csr draws with CPython's `random` (the un-JIT'd reference's stream, utils.py:119-136 /
+    numba_csr_functions.py:92-112); the bulk form (numpy's MT19937 loaded with `random`'s state) returns the loop's labels
+    and leaves `random` in the loop's state."""
+    import random
+
+    from xcolumns_amd import utils
+    for n, m, k in ((3000, 40, 8), (4000, 3000, 6), (2500, 500_000, 5), (5000, 130, 3)):
+        for seed in (1, 2):
+            random.seed(seed)
+            a = utils._random_at_k_loop(n, m, k)
+            sa = random.getstate()
+            random.seed(seed)
+            b = utils._random_at_k_vectorised(n, m, k)
+            assert b is not None and np.array_equal(a, b) and random.getstate() == sa, (n, m, k, seed)
+    assert utils._random_at_k_vectorised(100, 7, 5) is None      # m - t changes its bit length within a row: the loop
+    P = utils.random_at_k_csr((5000, 3000), 6, dtype=np.float32, seed=3)
+    random.seed(3)
+    ref = utils._random_at_k_loop(5000, 3000, 6).reshape(5000, 6)
+    ref.sort(axis=1)
+    assert np.array_equal(P.indices.reshape(5000, 6), ref)

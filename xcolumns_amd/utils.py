@@ -80,6 +80,16 @@ def random_at_k_csr(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[i
     n, m = shape
     if seed is not None:
         random.seed(seed)
+    indices = _random_at_k_vectorised(n, m, k) if n * k >= 4096 else None
+    if indices is None:
+        indices = _random_at_k_loop(n, m, k)
+    indptr = (np.arange(n + 1, dtype=np.int64) * k).astype(np.int32)
+    return construct_csr_matrix(np.ones(n * k, dtype=np.float32).astype(dtype), indices, indptr,
+                                dtype=dtype, shape=shape, sort_indices=True)
+
+
+def _random_at_k_loop(n: int, m: int, k: int) -> np.ndarray:
+    """numba_csr_functions.py:92-112 on CPython's `random`, row by row."""
     indices = np.empty(n * k, dtype=np.int32)
     randint = random.randint
     for i in range(n):
@@ -92,9 +102,66 @@ def random_at_k_csr(shape: Tuple[int, int], k: int, dtype=None, seed: Optional[i
             vt, vj = moved.get(t, t), moved.get(j, j)
             moved[j] = vt
             indices[row + t] = vj          # position t is final: later steps swap positions > t only
-    indptr = (np.arange(n + 1, dtype=np.int64) * k).astype(np.int32)
-    return construct_csr_matrix(np.ones(n * k, dtype=np.float32).astype(dtype), indices, indptr,
-                                dtype=dtype, shape=shape, sort_indices=True)
+    return indices
+
+
+def _random_at_k_vectorised(n: int, m: int, k: int) -> Optional[np.ndarray]:
+    """The same draws without a Python call per draw: `random.randint(t, m - 1)` is t + _randbelow(m - t), and _randbelow(w)
+    takes 32-bit Mersenne-Twister outputs >> (32 - w.bit_length()) until one is < w.  numpy's MT19937 is the same generator:
+    loaded with `random`'s state it yields the same outputs in bulk; a candidate below m - k + 1 is taken at every step and
+    one >= m at none, the few in between are settled in order; then the k swaps per row as array operations.  `random` is
+    left where the loop would have left it.  None: not applicable (the caller takes the loop)."""
+    if k < 1 or m - k + 1 < 1 or (m - k + 1).bit_length() != m.bit_length() or m.bit_length() > 32:
+        return None
+    try:
+        version, internal, gauss = random.getstate()
+        if version != 3 or len(internal) != 625:
+            return None
+        key, pos = np.asarray(internal[:624], dtype=np.uint32), int(internal[624])
+        bg = np.random.MT19937()
+        bg.state = {"bit_generator": "MT19937", "state": {"key": key, "pos": pos}}
+        bits, need = m.bit_length(), n * k
+        p_take = (m - k + 1) / float(1 << bits)
+        total = int(need / p_take * 1.02) + 4096
+        raw = bg.random_raw(total).astype(np.uint64)
+        r = (raw >> np.uint64(32 - bits)).astype(np.int64)
+        sure = r < (m - k + 1)
+        maybe = np.nonzero((r >= m - k + 1) & (r < m))[0]
+        taken = sure.copy()
+        if maybe.size:
+            before = np.cumsum(sure) - sure          # sure candidates in front of each position
+            extra = 0
+            for q in maybe:                          # a handful: m - t depends on the step, i.e. on how many were taken so far
+                t = int(before[q] + extra) % k
+                if r[q] < m - t:
+                    taken[q] = True
+                    extra += 1
+        where = np.nonzero(taken)[0]
+        if where.size < need:
+            return None
+        where = where[:need]
+        consumed = int(where[-1]) + 1
+        J = r[where].reshape(n, k) + np.arange(k, dtype=np.int64)[None, :]      # j_t = t + _randbelow(m - t)
+        # `random` ends where the loop would have ended: the same state stepped `consumed` outputs
+        bg.state = {"bit_generator": "MT19937", "state": {"key": key, "pos": pos}}
+        bg.random_raw(consumed)
+        st = bg.state["state"]
+        random.setstate((3, tuple(int(x) for x in st["key"]) + (int(st["pos"]),), gauss))
+        out = np.empty((n, k), dtype=np.int64)
+        VT = np.empty((n, k), dtype=np.int64)        # the value step t moved to position j_t
+        for t in range(k):
+            j = J[:, t]
+            vj, vt = j.copy(), np.full(n, t, dtype=np.int64)
+            for s_ in range(t):                      # the latest earlier step that wrote the position decides
+                hit = J[:, s_] == j
+                vj[hit] = VT[hit, s_]
+                hit = J[:, s_] == t
+                vt[hit] = VT[hit, s_]
+            VT[:, t] = vt
+            out[:, t] = vj
+        return out.reshape(-1).astype(np.int32)
+    except Exception:
+        return None
 
 
 def unpack_csr_matrix(matrix: csr_matrix):
