@@ -223,6 +223,13 @@ class WavePolicy:
             # wavefronts (the sweep after a greedy or random start on 22 K x 7 K Zipf: 54 wavefronts, 0.8-1.3e-5)
             if skewed and self.parity == "per_sweep" and not self.fixed:
                 self.sequential_below = 64
+            # round 3: on ANY shape.  A sweep the rule leaves a handful of wavefronts is both off the bar (25 K x 7 K, hmean after
+            # a greedy start: 1.1e-5 at 5-9 wavefronts, the concurrent fuzz) and slower than the exact sweep, now that the exact
+            # sweep is the ordered parallel one (a wavefront takes ~2.6 us per row: 7 ms for 25 K rows on 9 of them, 1-2 ms exact)
+            if self.parity == "per_sweep" and not self.fixed:
+                self.sequential_below = 64
+                if self.num * self.first_factor / (self.n * self.first_changed) < 64.0:
+                    self.first_sequential = True
         self.budget = self.num / (float(self.n) * float(self.n))   # the same rule as a share of n (diagnostics)
         info = _lib.device_info()
         self.cap = info["cu_count"] * info["waves_per_cu"]
