@@ -373,3 +373,37 @@ def test_random_at_k_csr_vectorised_is_the_loop():
     ref = utils._random_at_k_loop(5000, 3000, 6).reshape(5000, 6)
     ref.sort(axis=1)
     assert np.array_equal(P.indices.reshape(5000, 6), ref)
+
+
+def test_order_source_choice_depends_on_size_and_host(monkeypatch):
+    """block_coordinate._orders_on_device: the device generator costs 0.28 ms + 0.25 ns per row and order, the host walk
+    host_ns per row (measured once per process): a fast host keeps small matrices, the GPU takes large ones and every size on
+    a slow host; XCOLUMNS_ORDER_DEVICE forces either."""
+    from xcolumns_amd import block_coordinate as bc
+    monkeypatch.delenv("XCOLUMNS_ORDER_DEVICE", raising=False)
+    monkeypatch.setattr(bc, "_order_choice", 1.3)            # ns per row on a fast idle core
+    assert not bc._orders_on_device(100_000) and not bc._orders_on_device(150_000) and bc._orders_on_device(1_000_000)
+    monkeypatch.setattr(bc, "_order_choice", 4.0)            # a slow or busy host
+    assert bc._orders_on_device(100_000) and bc._orders_on_device(1_000_000)
+    monkeypatch.setattr(bc, "_order_choice", float("inf"))   # the host walk is not usable
+    assert bc._orders_on_device(60_000)
+    monkeypatch.setenv("XCOLUMNS_ORDER_DEVICE", "0")
+    assert not bc._orders_on_device(10_000_000)
+    monkeypatch.setenv("XCOLUMNS_ORDER_DEVICE", "1")
+    assert bc._orders_on_device(10)
+
+
+def test_wave_policy_exact_below_64_wavefronts_on_any_shape():
+    """Round 3: a sweep the width rule leaves fewer than 64 wavefronts runs exact (bca_parity="per_sweep"), skewed or not,
+    first sweep or later; "final" parity and fixed widths are left alone."""
+    orig = bc._lib.device_info
+    bc._lib.device_info = lambda: {"cu_count": 256, "waves_per_cu": 32}
+    try:
+        p = bc.WavePolicy(25_000, m=7_000, row_nnz=32, k=4, first_changed=1.0, scale=0.25)      # a greedy / random start
+        assert p.sequential_below == 64 and p.first_sequential and p.next(None) == 1 and p.next(20_000) == 1
+        assert p.next(100) > 64
+        f = bc.WavePolicy(25_000, m=7_000, row_nnz=32, k=4, first_changed=1.0, scale=0.25, parity="final")
+        assert f.sequential_below == 0 and f.next(20_000) >= 1
+        assert bc.WavePolicy(25_000, m=7_000, row_nnz=32, k=4, fixed=5).next(20_000) == 5
+    finally:
+        bc._lib.device_info = orig
