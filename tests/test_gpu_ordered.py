@@ -118,3 +118,46 @@ def test_ordered_is_the_default_where_the_policy_wants_the_exact_sweep(oref):
     assert mg["wavefronts"] == [1, 1, 1]
     assert np.abs(np.asarray(mg["utilities"]) - np.asarray(mo["utilities"])).max() < 1e-12
     _same(Pg, Po)
+
+
+def test_ordered_small_random_problems(oref):
+    """Sixty random small problems (the generator of tests/studies/fuzz_exact.py: 1-400 rows, ragged rows, a third of them
+    with values on a grid of eighths -- exact ties --, every metric, top / random starts, sum and mean aggregation, both
+    directions): the ordered parallel sweep behind bca_waves=1 returns the sequential oracle's labels and utilities."""
+    import xcolumns_amd.block_coordinate as bc
+    metrics = [("binary_precision_on_conf_matrix", oref.PRECISION), ("binary_recall_on_conf_matrix", oref.RECALL),
+               ("binary_f1_score_on_conf_matrix", oref.FBETA), ("binary_jaccard_score_on_conf_matrix", oref.JACCARD),
+               ("binary_balanced_accuracy_on_conf_matrix", oref.BALANCED_ACC)]
+    seen = []
+    orig = bc.BcaCsrEngine.sweep_ordered
+
+    def spy(self, order, n_order):
+        orig(self, order, n_order)
+        seen.append(self.ordered_stats["error"])
+
+    bc.BcaCsrEngine.sweep_ordered = spy
+    try:
+        for seed in range(60):
+            rng = np.random.default_rng(70_000 + seed)
+            n, m = int(rng.integers(2, 400)), int(rng.integers(2, 300))
+            k = int(rng.integers(1, min(m, 12) + 1))
+            rmax = int(rng.integers(k, min(m, 70) + 1))
+            lens = rng.integers(k, rmax + 1, size=n)
+            cols = np.concatenate([np.sort(rng.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
+            vals = (rng.integers(1, 9, size=cols.size) / 8.0) if rng.random() < 0.35 else rng.random(cols.size) ** rng.integers(1, 4)
+            Y = csr_matrix((vals.astype(np.float32), cols, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)), shape=(n, m))
+            name, base = metrics[int(rng.integers(len(metrics)))]
+            maximize = bool(rng.random() < 0.85)
+            kw = dict(seed=int(rng.integers(1000)), max_iters=int(rng.integers(1, 4)), tolerance=-1.0 if maximize else 1.0,
+                      skip_tn=base != oref.BALANCED_ACC and bool(rng.random() < 0.5), maximize=maximize,
+                      metric_aggregation=str(rng.choice(["mean", "sum"])), init_y_pred=str(rng.choice(["top", "random"])))
+            metric = oref.make_metric(base, k=float(k), m=float(m))
+            Po, mo = oref.predict_using_bc_with_0approx(Y, metric, k, **kw)
+            Pg, mg = bc.predict_using_bc_with_0approx(Y, getattr(bc, name), k, return_meta=True, bca_waves=1, **kw)
+            assert mg["iters"] == mo["iters"], (seed, kw)
+            assert np.allclose(mg["utilities"], mo["utilities"], rtol=1e-13, atol=1e-12), (seed, name, kw, mg["utilities"], mo["utilities"])
+            assert np.array_equal(Pg.indices, Po.indices), (seed, name, kw)
+    finally:
+        bc.BcaCsrEngine.sweep_ordered = orig
+    assert len(seen) >= 60 and all(e in (0, 1, 3) for e in seen)     # the ordered sweep ran (1 / 3: handed the rest to one wavefront)
+    print("ordered sweeps:", len(seen), "handed over:", sum(e != 0 for e in seen))
